@@ -1,0 +1,330 @@
+"""ctypes binding of libhp3d.so (include/hp3d.h) -- the only bridge between the Python call
+surface and the HIP engine.  No torch, no numpy fallback: if the library is missing or no GPU is
+visible, the product path raises.
+
+HP3D_LIB=<path> overrides the library (the CPU test-suite points it at tests/emu/libhp3d_emu.so,
+an interpreter of the same kernel sources; see tests/emu/hp3d_emu.h).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, 'libhp3d.so')
+
+VARIANTS = {'direct': 0, 'bottleneck': 1, 'proposed': 2}
+NET_SEG, NET_POSE, NET_PRIOR, NET_VP, NET_BOTTLENECK = 1, 2, 4, 8, 16
+
+_f = C.POINTER(C.c_float)
+_i32 = C.POINTER(C.c_int32)
+_ctx = C.c_void_p
+
+_SIGNATURES = {
+    'hp3d_abi_version': (C.c_int, []),
+    'hp3d_create': (C.c_int, [C.c_int, C.POINTER(_ctx)]),
+    'hp3d_destroy': (C.c_int, [_ctx]),
+    'hp3d_last_error': (C.c_char_p, [_ctx]),
+    'hp3d_stream': (C.c_void_p, [_ctx]),
+    'hp3d_sync': (C.c_int, [_ctx]),
+    'hp3d_set_option': (C.c_int, [_ctx, C.c_char_p, C.c_char_p]),
+    'hp3d_set_weight': (C.c_int, [_ctx, C.c_char_p, _f, C.POINTER(C.c_int64), C.c_int]),
+    'hp3d_finalize_weights': (C.c_int, [_ctx, C.c_int]),
+    'hp3d_weights_blob_bytes': (C.c_int, [_ctx, C.POINTER(C.c_size_t)]),
+    'hp3d_weights_blob_export': (C.c_int, [_ctx, C.c_void_p]),
+    'hp3d_weights_blob_import': (C.c_int, [_ctx, C.c_void_p, C.c_int]),
+    'hp3d_nets_mask': (C.c_int, [_ctx]),
+    'hp3d_infer_full': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
+    'hp3d_infer_full_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
+    'hp3d_infer_2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    'hp3d_handsegnet': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3),
+    'hp3d_posenet2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    'hp3d_posenet2d_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
+    'hp3d_poseprior': (C.c_int, [_ctx, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    'hp3d_pose3d': (C.c_int, [_ctx, C.c_int] + [C.c_void_p] * 5),
+    'hp3d_conv2d': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                              C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_maxpool2': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_avgpool8': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_resize_bilinear': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_crop_and_resize': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_void_p]),
+    'hp3d_mask_from_scoremap': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    'hp3d_fc': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_argmax2d': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_set_profiling': (C.c_int, [_ctx, C.c_int]),
+    'hp3d_prof_count': (C.c_int, [_ctx]),
+    'hp3d_prof_get': (C.c_int, [_ctx, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float),
+                                C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+}
+EXPORTS = tuple(sorted(_SIGNATURES))
+
+_lib = None
+_lib_path = None
+
+
+class Hp3dError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.environ.get('HP3D_LIB', DEFAULT_LIB)
+
+
+def load(path=None):
+    """dlopen the engine and attach prototypes.  Raises if the library is absent: there is no
+    Python/NumPy fallback for the product path."""
+    global _lib, _lib_path
+    path = path or lib_path()
+    if _lib is not None and _lib_path == path:
+        return _lib
+    if not os.path.exists(path):
+        raise Hp3dError("HIP engine library not found at %s -- build it with `python -m hand3d_amd.build` "
+                        "(hipcc, gfx950). The product has no CPU fallback." % path)
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if include/hp3d.h and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Engine(object):
+    """One hp3d_ctx: a device, a stream, packed weights and a pre-allocated arena."""
+
+    def __init__(self, device=0, path=None):
+        self.lib = load(path)
+        h = _ctx()
+        rc = self.lib.hp3d_create(int(device), C.byref(h))
+        if rc != 0:
+            raise Hp3dError("hp3d_create(%d) failed: %s" % (device, self.lib.hp3d_last_error(None).decode()))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.hp3d_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            msg = self.lib.hp3d_last_error(self.h).decode()
+            if rc == -1:
+                raise AssertionError(msg)            # the reference's bare asserts
+            if rc == -4:
+                raise NotImplementedError(msg)
+            raise Hp3dError("hp3d error %d: %s" % (rc, msg))
+
+    # -- options / weights -------------------------------------------------------------------
+    def set_option(self, key, value):
+        self._chk(self.lib.hp3d_set_option(self.h, key.encode(), value.encode()))
+
+    def set_weight(self, name, array):
+        a = _f32(array)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        self._chk(self.lib.hp3d_set_weight(self.h, name.encode(), a.ctypes.data_as(_f), shape, a.ndim))
+
+    def load_weight_dict(self, weight_dict):
+        for k in sorted(weight_dict):
+            self.set_weight(k, weight_dict[k])
+
+    def finalize_weights(self, dtype=0):
+        self._chk(self.lib.hp3d_finalize_weights(self.h, dtype))
+
+    def nets_mask(self):
+        return self.lib.hp3d_nets_mask(self.h)
+
+    def blob_bytes(self):
+        n = C.c_size_t()
+        self._chk(self.lib.hp3d_weights_blob_bytes(self.h, C.byref(n)))
+        return n.value
+
+    def blob_export(self, dev_ptr):
+        self._chk(self.lib.hp3d_weights_blob_export(self.h, C.c_void_p(dev_ptr)))
+
+    def blob_import(self, dev_ptr, nets_mask):
+        self._chk(self.lib.hp3d_weights_blob_import(self.h, C.c_void_p(dev_ptr), int(nets_mask)))
+
+    def sync(self):
+        self._chk(self.lib.hp3d_sync(self.h))
+
+    def stream(self):
+        return self.lib.hp3d_stream(self.h)
+
+    # -- whole-path --------------------------------------------------------------------------
+    def infer_full(self, image, hand_side, want_mask=False, outputs=('scoremap', 'crop', 'scale', 'center', 'kpmap', 'coord3d')):
+        image, hand_side = _f32(image), _f32(hand_side)
+        assert image.ndim == 4 and image.shape[3] == 3, "image must be [B,H,W,3]"
+        B, H, W, _ = image.shape
+        assert hand_side.shape == (B, 2), "hand_side must be [B,2]"
+        o = {
+            'scoremap': np.empty((B, H, W, 2), np.float32) if 'scoremap' in outputs else None,
+            'crop': np.empty((B, 256, 256, 3), np.float32) if 'crop' in outputs else None,
+            'scale': np.empty((B, 1), np.float32) if 'scale' in outputs else None,
+            'center': np.empty((B, 2), np.float32) if 'center' in outputs else None,
+            'kpmap': np.empty((B, 256, 256, 21), np.float32) if 'kpmap' in outputs else None,
+            'coord3d': np.empty((B, 21, 3), np.float32) if 'coord3d' in outputs else None,
+            'mask': np.empty((B, H, W), np.float32) if want_mask else None,
+        }
+        self._chk(self.lib.hp3d_infer_full(self.h, B, H, W, _ptr(image), _ptr(hand_side), _ptr(o['scoremap']),
+                                           _ptr(o['crop']), _ptr(o['scale']), _ptr(o['center']), _ptr(o['kpmap']),
+                                           _ptr(o['coord3d']), _ptr(o['mask'])))
+        return o
+
+    def infer_full_dev(self, B, H, W, image_ptr, hand_side_ptr, scoremap=0, crop=0, scale=0, center=0, kpmap=0,
+                       coord3d=0, mask=0):
+        """Device-pointer variant (ints); stream-ordered, call sync() before reading."""
+        v = lambda p: C.c_void_p(p) if p else None
+        self._chk(self.lib.hp3d_infer_full_dev(self.h, B, H, W, v(image_ptr), v(hand_side_ptr), v(scoremap), v(crop),
+                                               v(scale), v(center), v(kpmap), v(coord3d), v(mask)))
+
+    def infer_2d(self, image):
+        image = _f32(image)
+        assert image.ndim == 4 and image.shape[3] == 3, "image must be [B,H,W,3]"
+        B, H, W, _ = image.shape
+        kp = np.empty((B, 256, 256, 21), np.float32)
+        crop = np.empty((B, 256, 256, 3), np.float32)
+        scale = np.empty((B, 1), np.float32)
+        center = np.empty((B, 2), np.float32)
+        self._chk(self.lib.hp3d_infer_2d(self.h, B, H, W, _ptr(image), _ptr(kp), _ptr(crop), _ptr(scale), _ptr(center)))
+        return kp, crop, scale, center
+
+    def handsegnet(self, image, want_small=False):
+        image = _f32(image)
+        assert image.ndim == 4 and image.shape[3] == 3, "image must be [B,H,W,3]"
+        B, H, W, _ = image.shape
+        large = np.empty((B, H, W, 2), np.float32)
+        small = np.empty((B, H // 8, W // 8, 2), np.float32) if want_small else None
+        self._chk(self.lib.hp3d_handsegnet(self.h, B, H, W, _ptr(image), _ptr(large), _ptr(small)))
+        return (large, small) if want_small else large
+
+    def posenet2d(self, image_crop):
+        image_crop = _f32(image_crop)
+        assert image_crop.ndim == 4 and image_crop.shape[3] == 3, "image_crop must be [B,H,W,3]"
+        B, H, W, _ = image_crop.shape
+        outs = [np.empty((B, H // 8, W // 8, 21), np.float32) for _ in range(3)]
+        self._chk(self.lib.hp3d_posenet2d(self.h, B, H, W, _ptr(image_crop), *[_ptr(x) for x in outs]))
+        return outs
+
+    def poseprior(self, variant, scoremap256, hand_side):
+        if variant in ('local', 'local_w_xyz_loss'):
+            raise NotImplementedError("variant %r needs bone_rel_trafo_inv (SURVEY.md 8f N3)" % variant)
+        assert variant in VARIANTS, "Unknown variant."
+        sm, hs = _f32(scoremap256), _f32(hand_side)
+        assert sm.ndim == 4 and sm.shape[1:] == (256, 256, 21), "scoremap must be [B,256,256,21]"
+        B = sm.shape[0]
+        rel = np.empty((B, 21, 3), np.float32)
+        c3d = np.empty((B, 21, 3), np.float32)
+        R = np.empty((B, 3, 3), np.float32)
+        self._chk(self.lib.hp3d_poseprior(self.h, B, VARIANTS[variant], _ptr(sm), _ptr(hs), _ptr(rel), _ptr(c3d), _ptr(R)))
+        return rel, c3d, (R if variant == 'proposed' else None)
+
+    def pose3d(self, scoremap32, hand_side):
+        sm, hs = _f32(scoremap32), _f32(hand_side)
+        B = sm.shape[0]
+        assert sm.shape[1:] == (32, 32, 21)
+        rel = np.empty((B, 21, 3), np.float32)
+        can = np.empty((B, 21, 3), np.float32)
+        R = np.empty((B, 3, 3), np.float32)
+        self._chk(self.lib.hp3d_pose3d(self.h, B, _ptr(sm), _ptr(hs), _ptr(rel), _ptr(can), _ptr(R)))
+        return rel, can, R
+
+    # -- per-op ------------------------------------------------------------------------------
+    def conv2d(self, x, w, b, stride=1, act=True, pool=False):
+        x, w, b = _f32(x), _f32(w), _f32(b)
+        B, H, W, Cin = x.shape
+        k, _, _, Cout = w.shape
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        if pool:
+            Ho, Wo = Ho // 2, Wo // 2
+        out = np.empty((B, Ho, Wo, Cout), np.float32)
+        self._chk(self.lib.hp3d_conv2d(self.h, _ptr(x), B, H, W, Cin, _ptr(w), _ptr(b), k, stride, Cout, int(act),
+                                       int(pool), _ptr(out)))
+        return out
+
+    def maxpool2(self, x):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        out = np.empty((B, H // 2, W // 2, Cc), np.float32)
+        self._chk(self.lib.hp3d_maxpool2(self.h, _ptr(x), B, H, W, Cc, _ptr(out)))
+        return out
+
+    def avgpool8(self, x):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        out = np.empty((B, H // 8, W // 8, Cc), np.float32)
+        self._chk(self.lib.hp3d_avgpool8(self.h, _ptr(x), B, H, W, Cc, _ptr(out)))
+        return out
+
+    def resize_bilinear(self, x, oh, ow):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        out = np.empty((B, oh, ow, Cc), np.float32)
+        self._chk(self.lib.hp3d_resize_bilinear(self.h, _ptr(x), B, H, W, Cc, oh, ow, _ptr(out)))
+        return out
+
+    def crop_and_resize(self, image, center, scale, crop_size=256):
+        image, center, scale = _f32(image), _f32(center), _f32(scale).reshape(-1)
+        B, H, W, Cc = image.shape
+        out = np.empty((B, crop_size, crop_size, Cc), np.float32)
+        self._chk(self.lib.hp3d_crop_and_resize(self.h, _ptr(image), B, H, W, Cc, _ptr(center), _ptr(scale), crop_size,
+                                                _ptr(out)))
+        return out
+
+    def mask_from_scoremap(self, scoremap):
+        sm = _f32(scoremap)
+        B, H, W, c2 = sm.shape
+        assert c2 == 2
+        mask = np.empty((B, H, W), np.float32)
+        center = np.empty((B, 2), np.float32)
+        size = np.empty((B, 1), np.float32)
+        scale = np.empty((B, 1), np.float32)
+        seed = np.empty((B, 2), np.int32)
+        self._chk(self.lib.hp3d_mask_from_scoremap(self.h, _ptr(sm), B, H, W, _ptr(mask), _ptr(center), _ptr(size),
+                                                   _ptr(scale), _ptr(seed)))
+        return mask, center, size, scale, seed
+
+    def fc(self, x, w, b, act=False):
+        x, w, b = _f32(x), _f32(w), _f32(b)
+        B, Cin = x.shape
+        Cout = w.shape[1]
+        out = np.empty((B, Cout), np.float32)
+        self._chk(self.lib.hp3d_fc(self.h, _ptr(x), B, Cin, _ptr(w), _ptr(b), Cout, int(act), _ptr(out)))
+        return out
+
+    def argmax2d(self, x):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        out = np.empty((B, Cc, 2), np.int32)
+        self._chk(self.lib.hp3d_argmax2d(self.h, _ptr(x), B, H, W, Cc, _ptr(out)))
+        return out
+
+    # -- measurement -------------------------------------------------------------------------
+    def set_profiling(self, on):
+        self._chk(self.lib.hp3d_set_profiling(self.h, int(on)))
+
+    def profile(self):
+        """[(layer, kernel, ms, flops, bytes)] of the last whole-path call."""
+        n = self.lib.hp3d_prof_count(self.h)
+        rows = []
+        name, kern = C.create_string_buffer(96), C.create_string_buffer(96)
+        ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+        for i in range(n):
+            self._chk(self.lib.hp3d_prof_get(self.h, i, name, 96, kern, 96, C.byref(ms), C.byref(fl), C.byref(by)))
+            rows.append((name.value.decode(), kern.value.decode(), ms.value, fl.value, by.value))
+        return rows

@@ -1,0 +1,270 @@
+// conv_mfma.hip -- the hot kernel: NHWC float32 convolution as an implicit GEMM on the
+// gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, = an fmaf chain, 157 TF peak).
+//
+// Stands in for tf.nn.conv2d(SAME) + bias_add + leaky-ReLU (+ 2x2 max-pool) at every
+// NetworkOps.conv / conv_relu / max_pool call site of the reference
+// (utils/general.py:36-65; layer lists nets/ColorHandPose3DNetwork.py:144-161,183-214,255-258,291-294).
+//
+// Design (MI355X-first, not a cuDNN re-creation):
+//   * one workgroup = TH x TW output pixels of ONE image x BN output channels;
+//   * the input patch (with its k-1 halo) for a 32-channel slice is staged ONCE in LDS and all
+//     k*k filter taps are contracted out of it (the A operand is re-addressed, never re-loaded);
+//   * weights are pre-packed at load time into MFMA fragment order
+//        wpk[tap][Cin/8][Cout/32][h:2][n:32][j:4]   (h = lane>>5, n = lane&31)
+//     so the B fragment of a wave is ONE lane-linear ds_read_b128 and the global->LDS copy is a
+//     straight 16-B-per-lane stream;
+//   * the k index of each MFMA pair is permuted (lanes 0-31 take channels 8g..8g+3, lanes 32-63
+//     channels 8g+4..8g+7) so the A fragment is ONE ds_read_b128 per 4 MFMAs as well;
+//   * MFMA row r of a 32-pixel tile maps to pixel quad r>>2, (dy,dx) = ((r>>1)&1, r&1): the four
+//     accumulator registers 4a..4a+3 of a lane are one 2x2 pooling window -> the max-pool is a
+//     register-only epilogue;
+//   * next tap's weights are prefetched into registers while the current tap computes; one
+//     barrier per tap; two workgroups per CU hide the remaining staging latency.
+#include "hp3d_common.h"
+#include <cstdio>
+
+namespace {
+
+constexpr int CK = 32;        // channels per K-chunk
+constexpr int LDA = CK + 4;   // patch row pitch in floats (144 B: odd multiple of 16 B)
+
+template <int KS, int STRIDE, int TH, int TW, int WM, int WN, int MT, int NT>
+struct ConvCfg {
+    static constexpr int NTHR = 64 * WM * WN;
+    static constexpr int BM = TH * TW;
+    static constexpr int BN = WN * NT * 32;
+    static constexpr int PH = (TH - 1) * STRIDE + KS;
+    static constexpr int PW = (TW - 1) * STRIDE + KS;
+    static constexpr int PATCH_FLOATS = ((PH * PW * LDA + 3) / 4) * 4;
+    static constexpr int WBUF_FLOATS = CK * BN;
+    static constexpr int SMEM_BYTES = (PATCH_FLOATS + 2 * WBUF_FLOATS) * 4;
+    static constexpr int WVEC = (CK * BN / 4) / NTHR;   // float4 of weights per thread per tap
+    static_assert(BM == WM * MT * 32, "tile/wave mismatch");
+    static_assert(TH == WM * MT * (32 / TW), "tile rows mismatch");
+    static_assert(TW == 8 || TW == 16, "TW must be 8 or 16");
+    static_assert((CK * BN / 4) % NTHR == 0, "weight copy must divide evenly");
+};
+
+template <int KS, int STRIDE, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL>
+HP3D_KERNEL(64 * WM * WN)
+void conv_mfma_kernel(const ConvParams p) {
+    using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;
+    constexpr int NTHR = C::NTHR, BN = C::BN, PH = C::PH, PW = C::PW, TAPS = KS * KS;
+    constexpr int ROWS_PER_MT = 32 / TW;   // pixel rows covered by one 32-pixel MFMA tile
+    constexpr int QX = TW / 2;             // 2x2 quads per tile row
+
+    HP3D_DYN_SMEM(smem);
+    float* patch = smem;
+    float* wbuf = smem + C::PATCH_FLOATS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- which tile -------------------------------------------------------------------
+    int sp = blockIdx.x;
+    const int tx = sp % p.tiles_x; sp /= p.tiles_x;
+    const int ty = sp % p.tiles_y;
+    const int b = sp / p.tiles_y;
+    const int n0 = blockIdx.y * BN;
+    const int oy0 = ty * TH, ox0 = tx * TW;                 // tile origin (conv output coords)
+    const int gy0 = oy0 * STRIDE - p.pad_t, gx0 = ox0 * STRIDE - p.pad_l;   // patch origin (input coords)
+
+    const int C8 = p.Cin >> 3, CO32 = p.Cout >> 5;
+    const float* inb = p.in + (size_t)b * p.H * p.W * p.in_cs;
+
+    // ---- per-lane A fragment base offsets ---------------------------------------------
+    const int li = lane & 31, lh = lane >> 5;
+    int abase[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int t = wm * MT + mt;
+        const int q = li >> 2, dx = li & 1, dy = (li >> 1) & 1;
+        const int ly = t * ROWS_PER_MT + 2 * (q / QX) + dy;
+        const int lx = 2 * (q % QX) + dx;
+        abase[mt] = ((ly * STRIDE) * PW + lx * STRIDE) * LDA + lh * 4;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    f32x4 wreg[C::WVEC];
+    auto w_fetch = [&](int tap, int chunk) {
+#pragma unroll
+        for (int v = 0; v < C::WVEC; ++v) {
+            const int idx = tid + v * NTHR;          // float4 index inside the [CK x BN] tap tile
+            const int g = idx / (BN * 2);            // 8-channel group (BN*8 floats = BN*2 float4 each)
+            const int off = idx - g * (BN * 2);
+            const float* src = p.wpk + (((size_t)tap * C8 + (chunk * 4 + g)) * CO32 + (n0 >> 5)) * 256 + off * 4;
+            wreg[v] = *(const f32x4*)src;
+        }
+    };
+    auto w_commit = [&](float* dst) {
+#pragma unroll
+        for (int v = 0; v < C::WVEC; ++v) *(f32x4*)(dst + (tid + v * NTHR) * 4) = wreg[v];
+    };
+
+    const int nchunks = p.Cin / CK;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();   // everyone is done with the previous chunk's patch and weight buffers
+        // ---- stage the input patch for channels [chunk*32, chunk*32+32) ------------------
+        for (int idx = tid; idx < PH * PW * 8; idx += NTHR) {
+            const int pix = idx >> 3, c4 = idx & 7;
+            const int py = pix / PW, px = pix - py * PW;
+            const int gy = gy0 + py, gx = gx0 + px;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
+                v = *(const f32x4*)(inb + ((size_t)gy * p.W + gx) * p.in_cs + chunk * CK + c4 * 4);
+            *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
+        }
+        w_fetch(0, chunk);
+        w_commit(wbuf);
+        __syncthreads();
+
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const float* wb = wbuf + (tap & 1) * C::WBUF_FLOATS;
+            if (tap + 1 < TAPS) w_fetch(tap + 1, chunk);       // in flight during the MFMAs below
+            const int r = tap / KS, s = tap - r * KS;
+            const int toff = (r * PW + s) * LDA;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a[MT], bf[NT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(patch + abase[mt] + toff + g * 8);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bf[nt] = *(const f32x4*)(wb + g * (BN * 8) + (wn * NT + nt) * 256 + lane * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            acc[mt][nt] = HP3D_MFMA_32x32x2(a[mt][j], bf[nt][j], acc[mt][nt]);
+            }
+            if (tap + 1 < TAPS) {
+                w_commit(wbuf + ((tap + 1) & 1) * C::WBUF_FLOATS);
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store ------------------------
+    const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
+    float* outb = p.out + (size_t)b * Hs * Ws * p.out_cs;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int co = n0 + (wn * NT + nt) * 32 + li;
+        const float bias = p.bias[co];
+        const bool cok = co < p.cout_store;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int t = wm * MT + mt;
+#pragma unroll
+            for (int a4 = 0; a4 < 4; ++a4) {
+                const int q = 2 * a4 + lh;               // quad index of registers 4*a4..4*a4+3
+                const int qy = q / QX, qx = q % QX;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[mt][nt][a4 * 4 + e] + bias;
+                    if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                    v[e] = x;
+                }
+                if (POOL) {
+                    const int y = (oy0 + t * ROWS_PER_MT + 2 * qy) >> 1, x = (ox0 + 2 * qx) >> 1;
+                    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+                    if (cok && y < Hs && x < Ws) outb[((size_t)y * Ws + x) * p.out_cs + co] = m;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int y = oy0 + t * ROWS_PER_MT + 2 * qy + (e >> 1), x = ox0 + 2 * qx + (e & 1);
+                        if (cok && y < Hs && x < Ws) outb[((size_t)y * Ws + x) * p.out_cs + co] = v[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- instantiation table -----------------------------------------------------------------
+// tile configs: id 0: 8x16 x128  1: 8x16 x64  2: 8x16 x32  3: 8x8 x128  4: 8x8 x64  5: 8x8 x32
+template <int KS, int STRIDE, bool POOL>
+int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
+#define HP3D_CASE(id, TH, TW, WM, WN, MT, NT)                                                        \
+    case id: {                                                                                       \
+        using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;                                        \
+        auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, WM, WN, MT, NT, POOL>;                       \
+        static bool attr_done = false;                                                               \
+        if (!attr_done) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                C::SMEM_BYTES);                                                      \
+            attr_done = true;                                                                        \
+        }                                                                                            \
+        dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN);                                      \
+        HP3D_LAUNCH(kern, grid, dim3(C::NTHR), C::SMEM_BYTES, s, p);                                 \
+        return 0;                                                                                    \
+    }
+    switch (cfg) {
+        HP3D_CASE(0, 8, 16, 2, 2, 2, 2)
+        HP3D_CASE(1, 8, 16, 2, 2, 2, 1)
+        HP3D_CASE(2, 8, 16, 4, 1, 1, 1)
+        HP3D_CASE(3, 8, 8, 2, 2, 1, 2)
+        HP3D_CASE(4, 8, 8, 2, 2, 1, 1)
+        HP3D_CASE(5, 8, 8, 2, 1, 1, 1)
+    }
+#undef HP3D_CASE
+    return -1;
+}
+
+const int kCfgTH[6] = {8, 8, 8, 8, 8, 8};
+const int kCfgTW[6] = {16, 16, 16, 8, 8, 8};
+const int kCfgBN[6] = {128, 64, 32, 128, 64, 32};
+
+}  // namespace
+
+int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cout, int pool, int B, ConvPlan* plan) {
+    if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)) || (k == 7 && stride == 1))) return -1;
+    if (Cout % 32) return -1;
+    if (pool && !(k == 3 && stride == 1)) return -1;
+    const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : 32;
+    auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
+    // padded pixels computed by each tiling; prefer the wider tile unless it wastes >12% more
+    const long px16 = (long)cdiv(Ho, 8) * 8 * cdiv(Wo, 16) * 16;
+    const long px8 = (long)cdiv(Ho, 8) * 8 * cdiv(Wo, 8) * 8;
+    bool wide = (double)px16 <= 1.12 * (double)px8;
+    // under-filled chip: more, smaller workgroups
+    const long blocks16 = (long)B * cdiv(Ho, 8) * cdiv(Wo, 16) * (Cout / bn);
+    if (blocks16 < 512) wide = false;
+    plan->th = 8;
+    plan->tw = wide ? 16 : 8;
+    plan->bn = bn;
+    plan->variant = (wide ? 0 : 3) + (bn == 128 ? 0 : bn == 64 ? 1 : 2);
+    return 0;
+}
+
+int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s) {
+    const int cfg = plan.variant;
+    if (cfg < 0 || cfg > 5 || kCfgTW[cfg] != plan.tw || kCfgBN[cfg] != plan.bn) return -1;
+    if (k == 1 && stride == 1 && !pool) return launch_cfg<1, 1, false>(p, cfg, s);
+    if (k == 3 && stride == 1 && !pool) return launch_cfg<3, 1, false>(p, cfg, s);
+    if (k == 3 && stride == 1 && pool) return launch_cfg<3, 1, true>(p, cfg, s);
+    if (k == 3 && stride == 2 && !pool) return launch_cfg<3, 2, false>(p, cfg, s);
+    if (k == 7 && stride == 1 && !pool) return launch_cfg<7, 1, false>(p, cfg, s);
+    return -1;
+}
+
+const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan) {
+    static char buf[6 * 5 * 2][48];
+    static const int ks[5] = {1, 3, 3, 7, 3};
+    int kid = (k == 1) ? 0 : (k == 3 && stride == 1) ? 1 : (k == 3 && stride == 2) ? 2 : 3;
+    (void)ks;
+    char* b = buf[(plan.variant * 5 + kid) * 2 + (pool ? 1 : 0)];
+    snprintf(b, 48, "conv_mfma_k%ds%d_t%dx%d_n%d%s", k, stride, plan.th, plan.tw, plan.bn, pool ? "_pool" : "");
+    return b;
+}

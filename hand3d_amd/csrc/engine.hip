@@ -1,0 +1,1197 @@
+// engine.hip -- context, weight packing, stream-ordered executor and the C-ABI of libhp3d.so.
+// Host code only (the kernels live in conv_mfma.hip / glue.hip).  See include/hp3d.h for the
+// reference interfaces each entry point replaces.
+#include "hp3d_common.h"
+#include "../../include/hp3d.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_last_error;
+
+#define HP3D_FAIL(ctx, code, ...)                              \
+    do {                                                       \
+        char _b[512];                                          \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                 \
+        set_error((ctx), _b);                                  \
+        return (code);                                         \
+    } while (0)
+#define HIPCHK(ctx, expr)                                                                          \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) HP3D_FAIL(ctx, HP3D_ERR_HIP, "%s -> %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+#define CHK(expr)                     \
+    do {                              \
+        int _r = (expr);              \
+        if (_r != 0) return _r;       \
+    } while (0)
+
+enum { NET_SEG = 1, NET_POSE = 2, NET_PRIOR = 4, NET_VP = 8, NET_BOTTLENECK = 16 };
+
+// ---- layer tables (mirror hand3d_amd/arch.py; nets/ColorHandPose3DNetwork.py:144-161,183-214,255-267,291-307)
+struct ConvL {
+    std::string name;      // tf scope/layer, e.g. "HandSegNet/conv1_2"
+    int k, cin, cout, stride, relu;
+    int mode;              // 0 plain, 1 im2col first layer (Cin=3), 2 concat-permuted (conv6_1/conv7_1)
+    // packed geometry
+    int ek, cin_pad, cout_pad;
+    size_t w_off, b_off;   // offsets into the blob (floats)
+    int net;
+};
+struct FcL {
+    std::string name;
+    int cin, cout, relu;
+    size_t w_off, b_off;
+    int net;
+};
+
+int pad32(int c) { return (c + 31) / 32 * 32; }
+
+struct Tables {
+    std::vector<ConvL> conv;
+    std::vector<FcL> fc;
+    std::map<std::string, int> conv_idx, fc_idx;
+    size_t blob_floats = 0;
+
+    void add_conv(const char* scope, const char* name, int k, int cin, int cout, int stride, int relu, int net) {
+        ConvL l;
+        l.name = std::string(scope) + "/" + name;
+        l.k = k; l.cin = cin; l.cout = cout; l.stride = stride; l.relu = relu; l.net = net;
+        l.mode = (cin == 3) ? 1 : (cin == 149) ? 2 : 0;
+        l.ek = (l.mode == 1) ? 1 : k;
+        l.cin_pad = (l.mode == 1) ? 32 : (l.mode == 2) ? 160 : pad32(cin);
+        l.cout_pad = pad32(cout);
+        l.w_off = blob_floats;
+        blob_floats += (size_t)l.ek * l.ek * l.cin_pad * l.cout_pad;
+        l.b_off = blob_floats;
+        blob_floats += l.cout_pad;
+        conv_idx[l.name] = (int)conv.size();
+        conv.push_back(l);
+    }
+    void add_fc(const char* scope, const char* name, int cin, int cout, int relu, int net) {
+        FcL l;
+        l.name = std::string(scope) + "/" + name;
+        l.cin = cin; l.cout = cout; l.relu = relu; l.net = net;
+        l.w_off = blob_floats;
+        blob_floats += ((size_t)cin * cout + 3) / 4 * 4;
+        l.b_off = blob_floats;
+        blob_floats += (cout + 3) / 4 * 4;
+        fc_idx[l.name] = (int)fc.size();
+        fc.push_back(l);
+    }
+    Tables() {
+        char nm[32];
+        {   // HandSegNet
+            const int nl[4] = {2, 2, 4, 4}, ch[4] = {64, 128, 256, 512};
+            int cin = 3;
+            for (int b = 0; b < 4; ++b)
+                for (int i = 0; i < nl[b]; ++i) {
+                    snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i + 1);
+                    add_conv("HandSegNet", nm, 3, cin, ch[b], 1, 1, NET_SEG);
+                    cin = ch[b];
+                }
+            add_conv("HandSegNet", "conv5_1", 3, 512, 512, 1, 1, NET_SEG);
+            add_conv("HandSegNet", "conv5_2", 3, 512, 128, 1, 1, NET_SEG);
+            add_conv("HandSegNet", "conv6_1", 1, 128, 512, 1, 1, NET_SEG);
+            add_conv("HandSegNet", "conv6_2", 1, 512, 2, 1, 0, NET_SEG);
+        }
+        {   // PoseNet2D
+            const int nl[4] = {2, 2, 4, 2}, ch[4] = {64, 128, 256, 512};
+            int cin = 3;
+            for (int b = 0; b < 4; ++b)
+                for (int i = 0; i < nl[b]; ++i) {
+                    snprintf(nm, sizeof nm, "conv%d_%d", b + 1, i + 1);
+                    add_conv("PoseNet2D", nm, 3, cin, ch[b], 1, 1, NET_POSE);
+                    cin = ch[b];
+                }
+            add_conv("PoseNet2D", "conv4_3", 3, 512, 256, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv4_4", 3, 256, 256, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv4_5", 3, 256, 256, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv4_6", 3, 256, 256, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv4_7", 3, 256, 128, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv5_1", 1, 128, 512, 1, 1, NET_POSE);
+            add_conv("PoseNet2D", "conv5_2", 1, 512, 21, 1, 0, NET_POSE);
+            for (int p = 6; p <= 7; ++p) {
+                int c = 149;
+                for (int r = 1; r <= 5; ++r) {
+                    snprintf(nm, sizeof nm, "conv%d_%d", p, r);
+                    add_conv("PoseNet2D", nm, 7, c, 128, 1, 1, NET_POSE);
+                    c = 128;
+                }
+                snprintf(nm, sizeof nm, "conv%d_6", p);
+                add_conv("PoseNet2D", nm, 1, 128, 128, 1, 1, NET_POSE);
+                snprintf(nm, sizeof nm, "conv%d_7", p);
+                add_conv("PoseNet2D", nm, 1, 128, 21, 1, 0, NET_POSE);
+            }
+        }
+        {   // PosePrior
+            const int ch[3] = {32, 64, 128};
+            int cin = 21;
+            for (int i = 0; i < 3; ++i) {
+                snprintf(nm, sizeof nm, "conv_pose_%d_1", i);
+                add_conv("PosePrior", nm, 3, cin, ch[i], 1, 1, NET_PRIOR);
+                snprintf(nm, sizeof nm, "conv_pose_%d_2", i);
+                add_conv("PosePrior", nm, 3, ch[i], ch[i], 2, 1, NET_PRIOR);
+                cin = ch[i];
+            }
+            add_fc("PosePrior", "fc_rel0", 2050, 512, 1, NET_PRIOR);
+            add_fc("PosePrior", "fc_rel1", 512, 512, 1, NET_PRIOR);
+            add_fc("PosePrior", "fc_xyz", 512, 63, 0, NET_PRIOR);
+            add_fc("PosePrior", "fc_bottleneck", 512, 30, 0, NET_BOTTLENECK);
+            add_fc("PosePrior", "fc_xyz#bn", 30, 63, 0, NET_BOTTLENECK);   // fc_xyz of the bottleneck variant
+        }
+        {   // ViewpointNet
+            const int ch[3] = {64, 128, 256};
+            int cin = 21;
+            for (int i = 0; i < 3; ++i) {
+                snprintf(nm, sizeof nm, "conv_vp_%d_1", i);
+                add_conv("ViewpointNet", nm, 3, cin, ch[i], 1, 1, NET_VP);
+                snprintf(nm, sizeof nm, "conv_vp_%d_2", i);
+                add_conv("ViewpointNet", nm, 3, ch[i], ch[i], 2, 1, NET_VP);
+                cin = ch[i];
+            }
+            add_fc("ViewpointNet", "fc_vp0", 4098, 256, 1, NET_VP);
+            add_fc("ViewpointNet", "fc_vp1", 256, 128, 1, NET_VP);
+            // fc_vp_ux / uy / uz ([128,1] each) are packed as one [128,3] matrix
+            add_fc("ViewpointNet", "fc_vp_u", 128, 3, 0, NET_VP);
+        }
+    }
+};
+
+struct HostVar {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+};
+
+struct ProfRec {
+    std::string name, kernel;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+
+}  // namespace
+
+struct hp3d_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    Tables T;
+    std::map<std::string, HostVar> vars;
+    float* blob = nullptr;     // device, T.blob_floats
+    int nets = 0;              // finalized nets mask
+    int empty_fltmax = 0;
+    int conv_naive = 0;
+    // debug copies of the unpacked HWIO weights for conv_impl=naive
+    std::map<std::string, float*> naive_w;
+
+    // arena
+    size_t act_floats = 0;     // capacity of bufA/bufB
+    float *bufA = nullptr, *bufB = nullptr, *col = nullptr;
+    size_t col_floats = 0;
+    int capB = 0;
+    float *d_image = nullptr, *d_hs = nullptr, *d_large = nullptr, *d_crop = nullptr, *d_center = nullptr,
+          *d_scale = nullptr, *d_cropsize = nullptr, *d_kpmap = nullptr, *d_coord = nullptr, *d_mask = nullptr,
+          *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
+          *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
+          *d_pooled = nullptr;
+    int* d_seed = nullptr;
+    unsigned long long* d_keys = nullptr;
+    unsigned char* d_det = nullptr;
+    size_t image_floats = 0, large_floats = 0, det_bytes = 0, pose_px = 0;
+
+    // profiling
+    int profiling = 0;
+    std::vector<ProfRec> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_next = 0;
+};
+
+namespace {
+
+void set_error(hp3d_ctx* ctx, const char* msg) {
+    g_last_error = msg;
+    if (ctx) ctx->err = msg;
+}
+
+template <typename T>
+int dev_realloc(hp3d_ctx* ctx, T** p, size_t count) {
+    if (*p) hipFree(*p);
+    *p = nullptr;
+    HIPCHK(ctx, hipMalloc((void**)p, count * sizeof(T)));
+    return 0;
+}
+
+hipEvent_t get_event(hp3d_ctx* ctx) {
+    if (ctx->event_next == ctx->event_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        ctx->event_pool.push_back(e);
+    }
+    return ctx->event_pool[ctx->event_next++];
+}
+
+struct ProfScope {
+    hp3d_ctx* ctx;
+    int idx = -1;
+    ProfScope(hp3d_ctx* c, const std::string& name, const char* kernel, double flops, double bytes) : ctx(c) {
+        if (!c->profiling) return;
+        ProfRec r{name, kernel, flops, bytes, get_event(c), get_event(c)};
+        hipEventRecord(r.e0, c->stream);
+        idx = (int)c->prof.size();
+        c->prof.push_back(r);
+    }
+    ~ProfScope() {
+        if (idx >= 0) hipEventRecord(ctx->prof[idx].e1, ctx->stream);
+    }
+};
+
+void prof_reset(hp3d_ctx* ctx) {
+    ctx->prof.clear();
+    ctx->event_next = 0;
+}
+
+// ---- weight packing ------------------------------------------------------------------------
+// wpk[tap][c8][co32][h][n][j] = W_hwio[tap][ref_channel(c8*8+h*4+j)][co32*32+n]   (conv_mfma.hip)
+void pack_conv(const ConvL& l, const float* w, const float* b, float* blob) {
+    float* wp = blob + l.w_off;
+    float* bp = blob + l.b_off;
+    const int taps = l.ek * l.ek, C8 = l.cin_pad / 8, CO32 = l.cout_pad / 32;
+    memset(wp, 0, sizeof(float) * (size_t)taps * l.cin_pad * l.cout_pad);
+    memset(bp, 0, sizeof(float) * l.cout_pad);
+    for (int co = 0; co < l.cout; ++co) bp[co] = b[co];
+    for (int tap = 0; tap < taps; ++tap)
+        for (int e = 0; e < l.cin_pad; ++e) {
+            // engine channel e -> (reference tap, reference channel)
+            int rtap = tap, rc = -1;
+            if (l.mode == 0) {
+                rc = (e < l.cin) ? e : -1;
+            } else if (l.mode == 1) {            // im2col: e = (r*3+s)*3 + c
+                if (e < 27) { rtap = e / 3; rc = e % 3; }
+            } else {                             // concat buffer: [encoding 0..127 | scoremap 128..148 | 0]
+                if (e < 128) rc = 21 + e;        // reference concat is [scoremap(21), encoding(128)]
+                else if (e < 149) rc = e - 128;
+            }
+            if (rc < 0) continue;
+            const int c8 = e >> 3, h = (e >> 2) & 1, j = e & 3;
+            const float* src = w + ((size_t)rtap * l.cin + rc) * l.cout;
+            for (int co = 0; co < l.cout; ++co) {
+                const int co32 = co >> 5, n = co & 31;
+                wp[((((size_t)tap * C8 + c8) * CO32 + co32) * 2 + h) * 128 + n * 4 + j] = src[co];
+            }
+        }
+}
+
+int find_var(hp3d_ctx* ctx, const std::string& name, const HostVar** out) {
+    auto it = ctx->vars.find(name);
+    if (it == ctx->vars.end()) return -1;
+    *out = &it->second;
+    return 0;
+}
+
+// ---- arena ---------------------------------------------------------------------------------
+int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
+    const size_t px = (size_t)B * std::max((size_t)H * W, (size_t)256 * 256);
+    const size_t act = px * 64;
+    if (act > ctx->act_floats) {
+        CHK(dev_realloc(ctx, &ctx->bufA, act));
+        CHK(dev_realloc(ctx, &ctx->bufB, act));
+        ctx->act_floats = act;
+    }
+    if (px * 32 > ctx->col_floats) {
+        CHK(dev_realloc(ctx, &ctx->col, px * 32));
+        ctx->col_floats = px * 32;
+    }
+    const size_t imgf = (size_t)B * H * W * 3;
+    if (imgf > ctx->image_floats) {
+        CHK(dev_realloc(ctx, &ctx->d_image, imgf));
+        ctx->image_floats = imgf;
+    }
+    const size_t largef = (size_t)B * H * W * 2;
+    if (largef > ctx->large_floats) {
+        CHK(dev_realloc(ctx, &ctx->d_large, largef));
+        CHK(dev_realloc(ctx, &ctx->d_mask, (size_t)B * H * W));
+        CHK(dev_realloc(ctx, &ctx->d_fg, (size_t)B * H * W));
+        CHK(dev_realloc(ctx, &ctx->d_segsmall, (size_t)B * (H / 8 + 1) * (W / 8 + 1) * 32));
+        ctx->large_floats = largef;
+    }
+    if ((size_t)B * H * W > ctx->det_bytes) {
+        CHK(dev_realloc(ctx, &ctx->d_det, (size_t)B * H * W));
+        ctx->det_bytes = (size_t)B * H * W;
+    }
+    if (B > ctx->capB) {
+        CHK(dev_realloc(ctx, &ctx->d_hs, (size_t)B * 2));
+        CHK(dev_realloc(ctx, &ctx->d_crop, (size_t)B * 256 * 256 * 3));
+        CHK(dev_realloc(ctx, &ctx->d_center, (size_t)B * 2));
+        CHK(dev_realloc(ctx, &ctx->d_scale, (size_t)B));
+        CHK(dev_realloc(ctx, &ctx->d_cropsize, (size_t)B));
+        CHK(dev_realloc(ctx, &ctx->d_kpmap, (size_t)B * 256 * 256 * 21));
+        CHK(dev_realloc(ctx, &ctx->d_pooled, (size_t)B * 32 * 32 * 32));
+        CHK(dev_realloc(ctx, &ctx->d_coord, (size_t)B * 63));
+        CHK(dev_realloc(ctx, &ctx->d_can, (size_t)B * 63));
+        CHK(dev_realloc(ctx, &ctx->d_rot, (size_t)B * 9));
+        CHK(dev_realloc(ctx, &ctx->d_u, (size_t)B * 4));
+        CHK(dev_realloc(ctx, &ctx->d_fcin, (size_t)B * 4100));
+        CHK(dev_realloc(ctx, &ctx->d_fc1, (size_t)B * 512));
+        CHK(dev_realloc(ctx, &ctx->d_fc2, (size_t)B * 512));
+        CHK(dev_realloc(ctx, &ctx->d_seed, (size_t)B * 2));
+        CHK(dev_realloc(ctx, &ctx->d_keys, (size_t)B));
+        ctx->capB = B;
+    }
+    return 0;
+}
+
+// concat / scoremap buffers depend on the PoseNet input size (h/8 x w/8)
+int ensure_pose_bufs(hp3d_ctx* ctx, int B, int hs, int ws) {
+    const size_t px = (size_t)B * hs * ws;
+    if (px > ctx->pose_px || !ctx->d_concat) {
+        CHK(dev_realloc(ctx, &ctx->d_concat, px * 160));
+        for (int i = 0; i < 3; ++i) CHK(dev_realloc(ctx, &ctx->d_sm[i], px * 32));
+        ctx->pose_px = px;
+    }
+    return 0;
+}
+
+void same_pad(int in, int k, int stride, int* out, int* before) {
+    *out = (in + stride - 1) / stride;
+    int total = (*out - 1) * stride + k - in;
+    if (total < 0) total = 0;
+    *before = total / 2;
+}
+
+// ---- one convolution layer -------------------------------------------------------------------
+// in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
+int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, int H, int W, float* out, int out_cs,
+             int pool, int* Ho_out, int* Wo_out) {
+    int Ho, Wo, pt, pl;
+    const int k = l.ek;
+    same_pad(H, k, l.stride, &Ho, &pt);
+    same_pad(W, k, l.stride, &Wo, &pl);
+    const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
+    const double bytes = 4.0 * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
+                                (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
+    if (ctx->conv_naive && l.mode == 0 && !pool) {
+        ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
+        conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
+                          l.relu, out, out_cs, Ho, Wo, pt, pl, ctx->stream);
+    } else {
+        ConvPlan plan;
+        if (conv_mfma_plan(k, l.stride, Ho, Wo, l.cout_pad, pool, B, &plan) != 0)
+            HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no conv_mfma variant for %s (k=%d s=%d)", l.name.c_str(), k, l.stride);
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.w_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl;
+        p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
+        p.act = l.relu;
+        ProfScope ps(ctx, l.name, conv_mfma_variant_name(k, l.stride, pool, plan), flops, bytes);
+        if (conv_mfma_launch(p, k, l.stride, pool, plan, ctx->stream) != 0)
+            HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed for %s", l.name.c_str());
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (Ho_out) *Ho_out = pool ? Ho / 2 : Ho;
+    if (Wo_out) *Wo_out = pool ? Wo / 2 : Wo;
+    return 0;
+}
+
+const ConvL& CL(hp3d_ctx* ctx, const char* name) { return ctx->T.conv[ctx->T.conv_idx.at(name)]; }
+const FcL& FL(hp3d_ctx* ctx, const char* name) { return ctx->T.fc[ctx->T.fc_idx.at(name)]; }
+
+// VGG-style trunk shared by HandSegNet and PoseNet2D: conv1_1 (im2col) ... through block 4's first
+// `n4` layers.  Returns the activation pointer / size after the trunk.
+int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H, int W, int n4, float** act, int* h,
+              int* w) {
+    char nm[64];
+    {
+        ProfScope ps(ctx, std::string(scope) + "/im2col", "im2col3x3", 0.0, 4.0 * B * H * W * (3 + 32));
+        im2col3x3_launch(image, B, H, W, ctx->col, ctx->stream);
+    }
+    float* a = ctx->bufA;
+    float* b = ctx->bufB;
+    int ch = 64, ih = H, iw = W;
+    snprintf(nm, sizeof nm, "%s/conv1_1", scope);
+    CHK(run_conv(ctx, CL(ctx, nm), ctx->col, 32, B, ih, iw, a, 64, 0, nullptr, nullptr));
+    const int nl[4] = {2, 2, 4, n4}, chs[4] = {64, 128, 256, 512};
+    for (int blk = 0; blk < 4; ++blk) {
+        for (int i = (blk == 0 ? 1 : 0); i < nl[blk]; ++i) {
+            snprintf(nm, sizeof nm, "%s/conv%d_%d", scope, blk + 1, i + 1);
+            const int pool = (blk < 3 && i == nl[blk] - 1) ? 1 : 0;
+            int oh, ow;
+            CHK(run_conv(ctx, CL(ctx, nm), a, ch, B, ih, iw, b, chs[blk], pool, &oh, &ow));
+            std::swap(a, b);
+            ch = chs[blk]; ih = oh; iw = ow;
+        }
+    }
+    *act = a; *h = ih; *w = iw;
+    return 0;
+}
+
+// HandSegNet (nets/ColorHandPose3DNetwork.py:131-168) -> d_segsmall [B,H/8,W/8,32] (channels 0,1 real)
+int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W) {
+    float* a; int h, w;
+    CHK(run_trunk(ctx, "HandSegNet", image, B, H, W, 4, &a, &h, &w));
+    float* b = (a == ctx->bufA) ? ctx->bufB : ctx->bufA;
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_1"), a, 512, B, h, w, b, 512, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_2"), b, 512, B, h, w, a, 128, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_1"), a, 128, B, h, w, b, 512, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_2"), b, 512, B, h, w, ctx->d_segsmall, 32, 0, nullptr, nullptr));
+    return 0;
+}
+
+// PoseNet2D (nets/ColorHandPose3DNetwork.py:170-219) -> d_sm[0..2] [B,h/8,w/8,32] (21 real channels)
+int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
+    float* a; int h, w;
+    CHK(run_trunk(ctx, "PoseNet2D", crop, B, H, W, 2, &a, &h, &w));
+    CHK(ensure_pose_bufs(ctx, B, h, w));
+    float* b = (a == ctx->bufA) ? ctx->bufB : ctx->bufA;
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_3"), a, 512, B, h, w, b, 256, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_4"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_5"), a, 256, B, h, w, b, 256, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_6"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr));
+    // encoding -> channels 0..127 of the concat buffer [B,h,w,160]
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_7"), a, 256, B, h, w, ctx->d_concat, 160, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_1"), ctx->d_concat, 160, B, h, w, a, 512, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_2"), a, 512, B, h, w, ctx->d_sm[0], 32, 0, nullptr, nullptr));
+    char nm[64];
+    const int npix = B * h * w;
+    for (int p = 0; p < 2; ++p) {
+        // x = concat([scoremap, encoding]) : scoremap (21 real + 11 zero) -> channels 128..159
+        copy_channels_launch(ctx->d_sm[p], npix, 32, 32, ctx->d_concat + 128, 160, ctx->stream);
+        const float* x = ctx->d_concat;
+        int xcs = 160;
+        float* o = a;
+        for (int r = 1; r <= 5; ++r) {
+            snprintf(nm, sizeof nm, "PoseNet2D/conv%d_%d", p + 6, r);
+            CHK(run_conv(ctx, CL(ctx, nm), x, xcs, B, h, w, o, 128, 0, nullptr, nullptr));
+            x = o; xcs = 128;
+            o = (o == a) ? b : a;
+        }
+        snprintf(nm, sizeof nm, "PoseNet2D/conv%d_6", p + 6);
+        CHK(run_conv(ctx, CL(ctx, nm), x, 128, B, h, w, o, 128, 0, nullptr, nullptr));
+        snprintf(nm, sizeof nm, "PoseNet2D/conv%d_7", p + 6);
+        CHK(run_conv(ctx, CL(ctx, nm), o, 128, B, h, w, ctx->d_sm[p + 1], 32, 0, nullptr, nullptr));
+    }
+    return 0;
+}
+
+int run_fc(hp3d_ctx* ctx, const FcL& l, const float* x, int B, int x_stride, float* out, int out_stride) {
+    ProfScope ps(ctx, l.name, "fc", 2.0 * l.cin * l.cout * B, 4.0 * ((double)l.cin * l.cout + (double)B * (l.cin + l.cout)));
+    fc_launch(x, B, l.cin, x_stride, ctx->blob + l.w_off, ctx->blob + l.b_off, l.cout, l.relu, out, out_stride,
+              ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+// _inference_pose3d_can (nets/ColorHandPose3DNetwork.py:249-272; bottleneck: nets/PosePriorNetwork.py:115-116)
+int run_poseprior_can(hp3d_ctx* ctx, const float* sm32 /*[B,32,32,32]*/, const float* hs, int B, int bottleneck,
+                      float* can) {
+    char nm[64];
+    const float* x = sm32;
+    int cs = 32, h = 32, w = 32;
+    float* a = ctx->bufA;
+    float* b = ctx->bufB;
+    const int ch[3] = {32, 64, 128};
+    for (int i = 0; i < 3; ++i) {
+        snprintf(nm, sizeof nm, "PosePrior/conv_pose_%d_1", i);
+        CHK(run_conv(ctx, CL(ctx, nm), x, cs, B, h, w, a, ch[i], 0, &h, &w));
+        snprintf(nm, sizeof nm, "PosePrior/conv_pose_%d_2", i);
+        CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
+        x = b; cs = ch[i];
+        std::swap(a, b);
+    }
+    // x: [B,4,4,128] contiguous == NHWC flatten (h,w,c)
+    concat_handside_launch(x, B, 2048, hs, ctx->d_fcin, ctx->stream);
+    CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel0"), ctx->d_fcin, B, 2050, ctx->d_fc1, 512));
+    CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel1"), ctx->d_fc1, B, 512, ctx->d_fc2, 512));
+    if (bottleneck) {
+        CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_bottleneck"), ctx->d_fc2, B, 512, ctx->d_fc1, 32));
+        CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_xyz#bn"), ctx->d_fc1, B, 32, can, 63));
+    } else {
+        CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_xyz"), ctx->d_fc2, B, 512, can, 63));
+    }
+    return 0;
+}
+
+// _rotation_estimation (nets/ColorHandPose3DNetwork.py:285-309) -> u [B,3]
+int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, float* u) {
+    char nm[64];
+    const float* x = sm32;
+    int cs = 32, h = 32, w = 32;
+    float* a = ctx->bufA;
+    float* b = ctx->bufB;
+    const int ch[3] = {64, 128, 256};
+    for (int i = 0; i < 3; ++i) {
+        snprintf(nm, sizeof nm, "ViewpointNet/conv_vp_%d_1", i);
+        CHK(run_conv(ctx, CL(ctx, nm), x, cs, B, h, w, a, ch[i], 0, &h, &w));
+        snprintf(nm, sizeof nm, "ViewpointNet/conv_vp_%d_2", i);
+        CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
+        x = b; cs = ch[i];
+        std::swap(a, b);
+    }
+    concat_handside_launch(x, B, 4096, hs, ctx->d_fcin, ctx->stream);
+    CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp0"), ctx->d_fcin, B, 4098, ctx->d_fc1, 256));
+    CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp1"), ctx->d_fc1, B, 256, ctx->d_fc2, 128));
+    CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp_u"), ctx->d_fc2, B, 128, u, 3));
+    return 0;
+}
+
+// _inference_pose3d (nets/ColorHandPose3DNetwork.py:221-247)
+int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant) {
+    CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
+    const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
+    if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
+    lift_epilogue_launch(ctx->d_u, ctx->d_can, hs, B, ctx->d_rot, ctx->d_coord, do_rot, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int need_nets(hp3d_ctx* ctx, int mask) {
+    if (!ctx->blob) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "weights not finalized (call hp3d_finalize_weights)");
+    if ((ctx->nets & mask) != mask)
+        HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "required network weights not loaded (have mask %d, need %d)", ctx->nets, mask);
+    return 0;
+}
+
+int check_img(hp3d_ctx* ctx, int B, int H, int W) {
+    if (B < 1 || H < 16 || W < 16 || (H % 8) || (W % 8))
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad shape B=%d H=%d W=%d (need B>=1, H,W multiples of 8, >=16)", B, H, W);
+    if ((size_t)3 * H * ((W + 31) / 32) * 4 > 160 * 1024 - 1024)
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "image %dx%d too large for the in-LDS mask growth", H, W);
+    return 0;
+}
+
+int copy_in(hp3d_ctx* ctx, float* dst, const float* src, size_t n, bool dev) {
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                               ctx->stream));
+    return 0;
+}
+int copy_out(hp3d_ctx* ctx, float* dst, const float* src, size_t n, bool dev) {
+    if (!dst) return 0;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, n * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost,
+                               ctx->stream));
+    return 0;
+}
+
+// stages 2-8 of the full path on device-resident image/hand_side
+int run_detect_and_crop(hp3d_ctx* ctx, const float* d_image, int B, int H, int W, int want_mask) {
+    CHK(run_handsegnet(ctx, d_image, B, H, W));
+    MaskBuffers mb{ctx->d_keys, ctx->d_det, nullptr};
+    {
+        ProfScope ps(ctx, "seg_upsample_softmax", "seg_upsample_softmax", 0.0, 4.0 * B * H * W * 2 + (double)B * H * W);
+        seg_upsample_softmax_launch(ctx->d_segsmall, B, H / 8, W / 8, 32, H, W, ctx->d_large, mb, ctx->stream);
+    }
+    {
+        ProfScope ps(ctx, "mask_grow", "mask_grow", 0.0, (double)B * H * W);
+        mask_grow_launch(mb, B, H, W, ctx->empty_fltmax, want_mask ? ctx->d_mask : nullptr, ctx->d_center,
+                         ctx->d_cropsize, ctx->d_scale, ctx->d_seed, ctx->stream);
+    }
+    {
+        ProfScope ps(ctx, "crop_and_resize", "crop_and_resize", 0.0, 4.0 * B * (H * W * 3 + 256 * 256 * 3));
+        crop_and_resize_launch(d_image, B, H, W, 3, ctx->d_center, ctx->d_scale, 256, ctx->d_crop, ctx->stream);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
+int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                    float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
+                    float* coord3d, float* hand_mask, bool dev) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image || !hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
+    CHK(check_img(ctx, B, H, W));
+    CHK(need_nets(ctx, NET_SEG | NET_POSE | NET_PRIOR | NET_VP));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, H, W));
+    prof_reset(ctx);
+    const float* d_img = image;
+    const float* d_hs = hand_side;
+    if (!dev) {
+        CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
+        CHK(copy_in(ctx, ctx->d_hs, hand_side, (size_t)B * 2, false));
+        d_img = ctx->d_image; d_hs = ctx->d_hs;
+    }
+    CHK(run_detect_and_crop(ctx, d_img, B, H, W, hand_mask != nullptr));
+    CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256));
+    CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED));
+    if (kp_scoremap) {
+        ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
+        resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, ctx->stream);
+    }
+    CHK(copy_out(ctx, hand_scoremap, ctx->d_large, (size_t)B * H * W * 2, dev));
+    CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, dev));
+    CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, dev));
+    CHK(copy_out(ctx, center, ctx->d_center, (size_t)B * 2, dev));
+    if (!dev) CHK(copy_out(ctx, kp_scoremap, ctx->d_kpmap, (size_t)B * 256 * 256 * 21, false));
+    CHK(copy_out(ctx, coord3d, ctx->d_coord, (size_t)B * 63, dev));
+    CHK(copy_out(ctx, hand_mask, ctx->d_mask, (size_t)B * H * W, dev));
+    if (!dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int posenet_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop, float* s0, float* s1, float* s2, bool dev) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image_crop) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image_crop is NULL");
+    CHK(check_img(ctx, B, H, W));
+    CHK(need_nets(ctx, NET_POSE));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, H, W));
+    prof_reset(ctx);
+    const float* d_img = image_crop;
+    if (!dev) {
+        CHK(copy_in(ctx, ctx->d_image, image_crop, (size_t)B * H * W * 3, false));
+        d_img = ctx->d_image;
+    }
+    CHK(run_posenet(ctx, d_img, B, H, W));
+    const int hs = H / 8, ws = W / 8, npix = B * hs * ws;
+    float* outs[3] = {s0, s1, s2};
+    for (int i = 0; i < 3; ++i) {
+        if (!outs[i]) continue;
+        float* dst = dev ? outs[i] : ctx->bufA;   // compact [npix,21] staging
+        copy_channels_launch(ctx->d_sm[i], npix, 21, 32, dst, 21, ctx->stream);
+        if (!dev) {
+            CHK(copy_out(ctx, outs[i], ctx->bufA, (size_t)npix * 21, false));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        }
+    }
+    HIPCHK(ctx, hipGetLastError());
+    if (!dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// scratch helpers for the per-op entry points (host in -> device -> host out)
+struct Scratch {
+    hp3d_ctx* ctx;
+    std::vector<void*> ptrs;
+    explicit Scratch(hp3d_ctx* c) : ctx(c) {}
+    ~Scratch() {
+        for (void* p : ptrs) hipFree(p);
+    }
+    template <typename T>
+    T* alloc(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return (T*)p;
+    }
+    template <typename T>
+    T* upload(const T* h, size_t n) {
+        T* d = alloc<T>(n);
+        if (d && hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return nullptr;
+        return d;
+    }
+};
+#define NN(ctx, p)                                                         \
+    do {                                                                   \
+        if (!(p)) HP3D_FAIL(ctx, HP3D_ERR_NOMEM, "scratch allocation/upload failed: %s", #p); \
+    } while (0)
+
+int finish_op(hp3d_ctx* ctx) {
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int hp3d_abi_version(void) { return 1; }
+
+int hp3d_create(int device, hp3d_ctx** out) {
+    if (!out) return HP3D_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(nullptr, "hp3d_create: no HIP device visible (the engine has no CPU fallback)");
+        return HP3D_ERR_HIP;
+    }
+    if (device < 0 || device >= n) {
+        set_error(nullptr, "hp3d_create: device index out of range");
+        return HP3D_ERR_ARG;
+    }
+    hp3d_ctx* ctx = new hp3d_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
+        set_error(nullptr, "hp3d_create: hipSetDevice/hipStreamCreate failed");
+        delete ctx;
+        return HP3D_ERR_HIP;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int hp3d_destroy(hp3d_ctx* ctx) {
+    if (!ctx) return HP3D_ERR_ARG;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    float** fp[] = {&ctx->blob, &ctx->bufA, &ctx->bufB, &ctx->col, &ctx->d_image, &ctx->d_hs, &ctx->d_large,
+                    &ctx->d_crop, &ctx->d_center, &ctx->d_scale, &ctx->d_cropsize, &ctx->d_kpmap, &ctx->d_coord,
+                    &ctx->d_mask, &ctx->d_segsmall, &ctx->d_concat, &ctx->d_sm[0], &ctx->d_sm[1], &ctx->d_sm[2],
+                    &ctx->d_can, &ctx->d_rot, &ctx->d_u, &ctx->d_fcin, &ctx->d_fc1, &ctx->d_fc2, &ctx->d_fg,
+                    &ctx->d_pooled};
+    for (float** p : fp)
+        if (*p) hipFree(*p);
+    if (ctx->d_seed) hipFree(ctx->d_seed);
+    if (ctx->d_keys) hipFree(ctx->d_keys);
+    if (ctx->d_det) hipFree(ctx->d_det);
+    for (auto& kv : ctx->naive_w) hipFree(kv.second);
+    for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return 0;
+}
+
+const char* hp3d_last_error(hp3d_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+void* hp3d_stream(hp3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int hp3d_sync(hp3d_ctx* ctx) {
+    if (!ctx) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
+    if (!ctx || !key || !value) return HP3D_ERR_ARG;
+    const std::string k(key), v(value);
+    if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
+    if (k == "conv_impl" && (v == "mfma" || v == "naive")) { ctx->conv_naive = (v == "naive"); return 0; }
+    HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown option %s=%s", key, value);
+}
+
+int hp3d_set_weight(hp3d_ctx* ctx, const char* tf_var_name, const float* data, const int64_t* shape, int rank) {
+    if (!ctx || !tf_var_name || !data || !shape || rank < 1 || rank > 4) return HP3D_ERR_ARG;
+    std::string name(tf_var_name);
+    const size_t slash = name.rfind('/');
+    if (slash == std::string::npos) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad variable name %s", tf_var_name);
+    const std::string layer = name.substr(0, slash), kind = name.substr(slash + 1);
+    if (kind != "weights" && kind != "biases") HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad variable name %s", tf_var_name);
+    std::vector<int64_t> want;
+    bool known = false;
+    auto ci = ctx->T.conv_idx.find(layer);
+    if (ci != ctx->T.conv_idx.end()) {
+        const ConvL& l = ctx->T.conv[ci->second];
+        want = (kind == "weights") ? std::vector<int64_t>{l.k, l.k, l.cin, l.cout} : std::vector<int64_t>{l.cout};
+        known = true;
+    } else if (layer == "ViewpointNet/fc_vp_ux" || layer == "ViewpointNet/fc_vp_uy" || layer == "ViewpointNet/fc_vp_uz") {
+        want = (kind == "weights") ? std::vector<int64_t>{128, 1} : std::vector<int64_t>{1};
+        known = true;
+    } else if (layer == "PosePrior/fc_xyz") {
+        // [512,63] (proposed/direct) or [30,63] (bottleneck variant, nets/PosePriorNetwork.py:115-116)
+        if (kind == "weights" && rank == 2 && shape[0] == 30) { want = {30, 63}; name = "PosePrior/fc_xyz#bn/weights"; }
+        else want = (kind == "weights") ? std::vector<int64_t>{512, 63} : std::vector<int64_t>{63};
+        known = true;
+    } else {
+        auto fi = ctx->T.fc_idx.find(layer);
+        if (fi != ctx->T.fc_idx.end()) {
+            const FcL& l = ctx->T.fc[fi->second];
+            want = (kind == "weights") ? std::vector<int64_t>{l.cin, l.cout} : std::vector<int64_t>{l.cout};
+            known = true;
+        }
+    }
+    if (!known) HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown variable %s", tf_var_name);
+    if ((int)want.size() != rank) HP3D_FAIL(ctx, HP3D_ERR_ARG, "rank mismatch for %s", tf_var_name);
+    size_t n = 1;
+    for (int i = 0; i < rank; ++i) {
+        if (shape[i] != want[i]) HP3D_FAIL(ctx, HP3D_ERR_ARG, "shape mismatch for %s (dim %d: got %lld want %lld)",
+                                           tf_var_name, i, (long long)shape[i], (long long)want[i]);
+        n *= (size_t)shape[i];
+    }
+    HostVar v;
+    v.data.assign(data, data + n);
+    v.shape.assign(shape, shape + rank);
+    ctx->vars[name] = std::move(v);
+    return 0;
+}
+
+int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (dtype != 0) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "only dtype 0 (f32) is implemented");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    std::vector<float> host(ctx->T.blob_floats, 0.f);
+    int have = 0, partial = 0, bn_ok = 0;
+    auto mark = [&](int net, bool present) {
+        if (present) have |= net; else partial |= net;
+    };
+    for (const ConvL& l : ctx->T.conv) {
+        const HostVar *w = nullptr, *b = nullptr;
+        const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, l.name + "/biases", &b) == 0;
+        mark(l.net, ok);
+        if (ok) pack_conv(l, w->data.data(), b->data.data(), host.data());
+    }
+    for (const FcL& l : ctx->T.fc) {
+        if (l.name == "ViewpointNet/fc_vp_u") {
+            const HostVar *w[3], *b[3];
+            const char* ax[3] = {"ux", "uy", "uz"};
+            bool ok = true;
+            for (int a = 0; a < 3; ++a)
+                ok = ok && find_var(ctx, std::string("ViewpointNet/fc_vp_") + ax[a] + "/weights", &w[a]) == 0 &&
+                     find_var(ctx, std::string("ViewpointNet/fc_vp_") + ax[a] + "/biases", &b[a]) == 0;
+            mark(l.net, ok);
+            if (ok)
+                for (int a = 0; a < 3; ++a) {
+                    for (int i = 0; i < 128; ++i) host[l.w_off + (size_t)i * 3 + a] = w[a]->data[i];
+                    host[l.b_off + a] = b[a]->data[0];
+                }
+            continue;
+        }
+        std::string bias_name = l.name + "/biases";
+        if (l.name == "PosePrior/fc_xyz#bn") bias_name = "PosePrior/fc_xyz/biases";
+        const HostVar *w = nullptr, *b = nullptr;
+        const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, bias_name, &b) == 0;
+        if (l.name == "PosePrior/fc_xyz") {
+            // absent in the bottleneck variant: not an error there
+            if (!ok && ctx->vars.count("PosePrior/fc_xyz#bn/weights")) continue;
+        }
+        if (l.net == NET_BOTTLENECK) { if (ok) ++bn_ok; }
+        else mark(l.net, ok);
+        if (ok) {
+            memcpy(&host[l.w_off], w->data.data(), sizeof(float) * (size_t)l.cin * l.cout);
+            memcpy(&host[l.b_off], b->data.data(), sizeof(float) * l.cout);
+        }
+    }
+    const int bad = have & partial & (NET_SEG | NET_POSE | NET_PRIOR | NET_VP);
+    if (bad) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "incomplete variable set for network mask %d", bad);
+    if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
+    HIPCHK(ctx, hipMemcpy(ctx->blob, host.data(), sizeof(float) * ctx->T.blob_floats, hipMemcpyHostToDevice));
+    ctx->nets = have & ~partial;
+    if (bn_ok == 2) ctx->nets |= NET_BOTTLENECK;
+    // raw HWIO copies for the debug conv (conv_impl=naive)
+    if (ctx->conv_naive)
+        for (const ConvL& l : ctx->T.conv) {
+            const HostVar* w = nullptr;
+            if (find_var(ctx, l.name + "/weights", &w) != 0) continue;
+            float* d = nullptr;
+            HIPCHK(ctx, hipMalloc((void**)&d, w->data.size() * sizeof(float)));
+            HIPCHK(ctx, hipMemcpy(d, w->data.data(), w->data.size() * sizeof(float), hipMemcpyHostToDevice));
+            if (ctx->naive_w.count(l.name)) hipFree(ctx->naive_w[l.name]);
+            ctx->naive_w[l.name] = d;
+        }
+    return 0;
+}
+
+int hp3d_weights_blob_bytes(hp3d_ctx* ctx, size_t* bytes) {
+    if (!ctx || !bytes) return HP3D_ERR_ARG;
+    *bytes = ctx->T.blob_floats * sizeof(float);
+    return 0;
+}
+int hp3d_weights_blob_export(hp3d_ctx* ctx, void* dev_dst) {
+    if (!ctx || !dev_dst) return HP3D_ERR_ARG;
+    if (!ctx->blob) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "weights not finalized");
+    HIPCHK(ctx, hipMemcpyAsync(dev_dst, ctx->blob, ctx->T.blob_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int hp3d_weights_blob_import(hp3d_ctx* ctx, const void* dev_src, int nets_mask) {
+    if (!ctx || !dev_src) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->blob, dev_src, ctx->T.blob_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nets = nets_mask;
+    return 0;
+}
+int hp3d_nets_mask(hp3d_ctx* ctx) { return ctx ? ctx->nets : 0; }
+
+int hp3d_infer_full(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                    float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                    float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask) {
+    return infer_full_impl(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                           keypoints_scoremap, keypoint_coord3d, hand_mask, false);
+}
+int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                        float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                        float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask) {
+    return infer_full_impl(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                           keypoints_scoremap, keypoint_coord3d, hand_mask, true);
+}
+
+int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
+                  float* image_crop, float* scale_crop, float* center) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image is NULL");
+    CHK(check_img(ctx, B, H, W));
+    CHK(need_nets(ctx, NET_SEG | NET_POSE));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, H, W));
+    prof_reset(ctx);
+    CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
+    CHK(run_detect_and_crop(ctx, ctx->d_image, B, H, W, 0));
+    CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256));
+    if (keypoints_scoremap) {
+        resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, ctx->d_kpmap, ctx->stream);
+        CHK(copy_out(ctx, keypoints_scoremap, ctx->d_kpmap, (size_t)B * 256 * 256 * 21, false));
+    }
+    CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, false));
+    CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, false));
+    CHK(copy_out(ctx, center, ctx->d_center, (size_t)B * 2, false));
+    return finish_op(ctx);
+}
+
+int hp3d_handsegnet(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* scoremap_large,
+                    float* scoremap_small) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image is NULL");
+    CHK(check_img(ctx, B, H, W));
+    CHK(need_nets(ctx, NET_SEG));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, H, W));
+    prof_reset(ctx);
+    CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
+    CHK(run_handsegnet(ctx, ctx->d_image, B, H, W));
+    if (scoremap_large) {
+        resize_bilinear_launch(ctx->d_segsmall, B, H / 8, W / 8, 2, 32, H, W, ctx->d_large, ctx->stream);
+        CHK(copy_out(ctx, scoremap_large, ctx->d_large, (size_t)B * H * W * 2, false));
+    }
+    if (scoremap_small) {
+        const int npix = B * (H / 8) * (W / 8);
+        copy_channels_launch(ctx->d_segsmall, npix, 2, 32, ctx->bufA, 2, ctx->stream);
+        CHK(copy_out(ctx, scoremap_small, ctx->bufA, (size_t)npix * 2, false));
+    }
+    return finish_op(ctx);
+}
+
+int hp3d_posenet2d(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop, float* s0, float* s1, float* s2) {
+    return posenet_impl(ctx, B, H, W, image_crop, s0, s1, s2, false);
+}
+int hp3d_posenet2d_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop, float* s0, float* s1, float* s2) {
+    return posenet_impl(ctx, B, H, W, image_crop, s0, s1, s2, true);
+}
+
+static int lift_common(hp3d_ctx* ctx, int B, int variant, const float* d_sm32pad, const float* hand_side,
+                       float* rel, float* can, float* rot) {
+    CHK(copy_in(ctx, ctx->d_hs, hand_side, (size_t)B * 2, false));
+    CHK(run_pose3d(ctx, d_sm32pad, ctx->d_hs, B, variant));
+    CHK(copy_out(ctx, rel, ctx->d_coord, (size_t)B * 63, false));
+    CHK(copy_out(ctx, can, ctx->d_can, (size_t)B * 63, false));
+    if (variant == HP3D_VARIANT_PROPOSED) CHK(copy_out(ctx, rot, ctx->d_rot, (size_t)B * 9, false));
+    return finish_op(ctx);
+}
+
+int hp3d_poseprior(hp3d_ctx* ctx, int B, int variant, const float* scoremap256, const float* hand_side,
+                   float* coord_xyz_rel_normed, float* coord3d, float* rot_mat) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!scoremap256 || !hand_side || B < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    if (variant < 0 || variant > 2) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "Unknown variant.");
+    CHK(need_nets(ctx, variant == HP3D_VARIANT_PROPOSED ? (NET_PRIOR | NET_VP)
+                       : variant == HP3D_VARIANT_BOTTLENECK ? (NET_PRIOR | NET_BOTTLENECK) : NET_PRIOR));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, 256, 256));
+    prof_reset(ctx);
+    // stage the [B,256,256,21] GT scoremaps in bufA, pool 8x8 into the padded [B,32,32,32] buffer
+    CHK(copy_in(ctx, ctx->bufB, scoremap256, (size_t)B * 256 * 256 * 21, false));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_pooled, 0, sizeof(float) * (size_t)B * 32 * 32 * 32, ctx->stream));
+    avgpool8_launch(ctx->bufB, B, 256, 256, 21, ctx->d_pooled, 32, ctx->stream);
+    // the lifting convs ping-pong through bufA/bufB; d_pooled is separate
+    return lift_common(ctx, B, variant, ctx->d_pooled, hand_side, coord_xyz_rel_normed, coord3d, rot_mat);
+}
+
+int hp3d_pose3d(hp3d_ctx* ctx, int B, const float* scoremap32, const float* hand_side, float* coord_xyz_rel_normed,
+                float* coord_can, float* rot_mat) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!scoremap32 || !hand_side || B < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    CHK(need_nets(ctx, NET_PRIOR | NET_VP));
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    CHK(ensure_arena(ctx, B, 256, 256));
+    prof_reset(ctx);
+    CHK(copy_in(ctx, ctx->bufB, scoremap32, (size_t)B * 32 * 32 * 21, false));
+    pad_channels_launch(ctx->bufB, B * 32 * 32, 21, ctx->d_pooled, 32, ctx->stream);
+    return lift_common(ctx, B, HP3D_VARIANT_PROPOSED, ctx->d_pooled, hand_side, coord_xyz_rel_normed, coord_can, rot_mat);
+}
+
+// ---- per-op entry points -----------------------------------------------------------------------
+int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, const float* w_hwio, const float* bias,
+                int k, int stride, int Cout, int act, int pool, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !w_hwio || !bias || !out || B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1)
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ConvL l;
+    l.name = "op/conv2d";
+    l.k = k; l.cin = Cin; l.cout = Cout; l.stride = stride; l.relu = act; l.net = 0;
+    l.mode = 0; l.ek = k; l.cin_pad = pad32(Cin); l.cout_pad = pad32(Cout);
+    l.w_off = 0; l.b_off = (size_t)k * k * l.cin_pad * l.cout_pad;
+    std::vector<float> packed(l.b_off + l.cout_pad);
+    pack_conv(l, w_hwio, bias, packed.data());
+    int Ho, Wo, pt, pl;
+    same_pad(H, k, stride, &Ho, &pt);
+    same_pad(W, k, stride, &Wo, &pl);
+    const int Hs = pool ? Ho / 2 : Ho, Ws = pool ? Wo / 2 : Wo;
+    Scratch S(ctx);
+    float* d_x = S.upload(x, (size_t)B * H * W * Cin); NN(ctx, d_x);
+    float* d_xp = d_x;
+    if (l.cin_pad != Cin) {
+        d_xp = S.alloc<float>((size_t)B * H * W * l.cin_pad); NN(ctx, d_xp);
+        pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
+    }
+    float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
+    if (ctx->conv_naive) {
+        if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");
+        float* d_w = S.upload(w_hwio, (size_t)k * k * Cin * Cout); NN(ctx, d_w);
+        float* d_b = S.upload(bias, (size_t)Cout); NN(ctx, d_b);
+        conv_naive_launch(d_x, B, H, W, Cin, Cin, d_w, d_b, k, stride, Cout, act, d_out, Cout, Ho, Wo, pt, pl, ctx->stream);
+    } else {
+        float* d_pk = S.upload(packed.data(), packed.size()); NN(ctx, d_pk);
+        ConvPlan plan;
+        if (conv_mfma_plan(k, stride, Ho, Wo, l.cout_pad, pool, B, &plan) != 0)
+            HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no conv_mfma variant for k=%d stride=%d pool=%d", k, stride, pool);
+        ConvParams p;
+        p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + l.b_off; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
+        p.pad_t = pt; p.pad_l = pl;
+        p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
+        p.act = act;
+        if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
+            HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");
+    }
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_maxpool2(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !out || B < 1 || H < 2 || W < 2 || C < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    const size_t no = (size_t)B * (H / 2) * (W / 2) * C;
+    float* d_x = S.upload(x, (size_t)B * H * W * C); NN(ctx, d_x);
+    float* d_o = S.alloc<float>(no); NN(ctx, d_o);
+    maxpool2_launch(d_x, B, H, W, C, C, d_o, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_avgpool8(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !out || B < 1 || (H % 8) || (W % 8) || C < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments (H,W %% 8)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    const size_t no = (size_t)B * (H / 8) * (W / 8) * C;
+    float* d_x = S.upload(x, (size_t)B * H * W * C); NN(ctx, d_x);
+    float* d_o = S.alloc<float>(no); NN(ctx, d_o);
+    avgpool8_launch(d_x, B, H, W, C, d_o, C, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_resize_bilinear(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int out_h, int out_w, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !out || B < 1 || H < 1 || W < 1 || C < 1 || out_h < 1 || out_w < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    const size_t no = (size_t)B * out_h * out_w * C;
+    float* d_x = S.upload(x, (size_t)B * H * W * C); NN(ctx, d_x);
+    float* d_o = S.alloc<float>(no); NN(ctx, d_o);
+    resize_bilinear_launch(d_x, B, H, W, C, C, out_h, out_w, d_o, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_crop_and_resize(hp3d_ctx* ctx, const float* image, int B, int H, int W, int C, const float* center,
+                         const float* scale, int crop_size, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image || !center || !scale || !out || B < 1 || H < 2 || W < 2 || C < 1 || crop_size < 1)
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    const size_t no = (size_t)B * crop_size * crop_size * C;
+    float* d_x = S.upload(image, (size_t)B * H * W * C); NN(ctx, d_x);
+    float* d_c = S.upload(center, (size_t)B * 2); NN(ctx, d_c);
+    float* d_s = S.upload(scale, (size_t)B); NN(ctx, d_s);
+    float* d_o = S.alloc<float>(no); NN(ctx, d_o);
+    crop_and_resize_launch(d_x, B, H, W, C, d_c, d_s, crop_size, d_o, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, no * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_mask_from_scoremap(hp3d_ctx* ctx, const float* scoremap, int B, int H, int W, float* mask, float* center,
+                            float* crop_size, float* scale, int32_t* seed) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!scoremap || B < 1 || H < 1 || W < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    if (!(B < H && B < W)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "Scoremap must be [Batch, Width, Height]");  // general.py:210
+    if ((size_t)3 * H * ((W + 31) / 32) * 4 > 160 * 1024 - 1024) HP3D_FAIL(ctx, HP3D_ERR_ARG, "map too large");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    const size_t npx = (size_t)B * H * W;
+    float* d_sm = S.upload(scoremap, npx * 2); NN(ctx, d_sm);
+    MaskBuffers mb;
+    mb.argmax_key = S.alloc<unsigned long long>(B); NN(ctx, mb.argmax_key);
+    mb.det = S.alloc<unsigned char>(npx); NN(ctx, mb.det);
+    mb.fg = nullptr;
+    float* d_mask = S.alloc<float>(npx); NN(ctx, d_mask);
+    float* d_c = S.alloc<float>((size_t)B * 2); NN(ctx, d_c);
+    float* d_cs = S.alloc<float>(B); NN(ctx, d_cs);
+    float* d_sc = S.alloc<float>(B); NN(ctx, d_sc);
+    int* d_seed = S.alloc<int>((size_t)B * 2); NN(ctx, d_seed);
+    seg_softmax_launch(d_sm, B, H, W, mb, ctx->stream);
+    mask_grow_launch(mb, B, H, W, ctx->empty_fltmax, d_mask, d_c, d_cs, d_sc, d_seed, ctx->stream);
+    if (mask) HIPCHK(ctx, hipMemcpyAsync(mask, d_mask, npx * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (center) HIPCHK(ctx, hipMemcpyAsync(center, d_c, sizeof(float) * B * 2, hipMemcpyDeviceToHost, ctx->stream));
+    if (crop_size) HIPCHK(ctx, hipMemcpyAsync(crop_size, d_cs, sizeof(float) * B, hipMemcpyDeviceToHost, ctx->stream));
+    if (scale) HIPCHK(ctx, hipMemcpyAsync(scale, d_sc, sizeof(float) * B, hipMemcpyDeviceToHost, ctx->stream));
+    if (seed) HIPCHK(ctx, hipMemcpyAsync(seed, d_seed, sizeof(int) * B * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_fc(hp3d_ctx* ctx, const float* x, int B, int Cin, const float* w, const float* bias, int Cout, int act,
+            float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !w || !bias || !out || B < 1 || Cin < 1 || Cout < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    float* d_x = S.upload(x, (size_t)B * Cin); NN(ctx, d_x);
+    float* d_w = S.upload(w, (size_t)Cin * Cout); NN(ctx, d_w);
+    float* d_b = S.upload(bias, (size_t)Cout); NN(ctx, d_b);
+    float* d_o = S.alloc<float>((size_t)B * Cout); NN(ctx, d_o);
+    fc_launch(d_x, B, Cin, Cin, d_w, d_b, Cout, act, d_o, Cout, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, sizeof(float) * (size_t)B * Cout, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+int hp3d_argmax2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int32_t* out_rc) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!x || !out_rc || B < 1 || H < 1 || W < 1 || C < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    float* d_x = S.upload(x, (size_t)B * H * W * C); NN(ctx, d_x);
+    int* d_o = S.alloc<int>((size_t)B * C * 2); NN(ctx, d_o);
+    argmax2d_launch(d_x, B, H, W, C, C, d_o, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out_rc, d_o, sizeof(int) * (size_t)B * C * 2, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+int hp3d_set_profiling(hp3d_ctx* ctx, int on) {
+    if (!ctx) return HP3D_ERR_ARG;
+    ctx->profiling = on ? 1 : 0;
+    if (!on) prof_reset(ctx);
+    return 0;
+}
+int hp3d_prof_count(hp3d_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }
+int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, int kernel_cap, float* ms,
+                  double* flops, double* bytes) {
+    if (!ctx || i < 0 || i >= (int)ctx->prof.size()) return HP3D_ERR_ARG;
+    const ProfRec& r = ctx->prof[i];
+    if (name && name_cap > 0) snprintf(name, name_cap, "%s", r.name.c_str());
+    if (kernel && kernel_cap > 0) snprintf(kernel, kernel_cap, "%s", r.kernel.c_str());
+    if (ms) {
+        HIPCHK(ctx, hipEventSynchronize(r.e1));
+        HIPCHK(ctx, hipEventElapsedTime(ms, r.e0, r.e1));
+    }
+    if (flops) *flops = r.flops;
+    if (bytes) *bytes = r.bytes;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,574 @@
+// glue.hip -- the HBM-bound / latency-bound stages between the MFMA convolutions.
+// Everything here is compiled with -ffp-contract=off: the reference evaluates these
+// expressions op by op in float32 (TF 1.3 CPU/GPU kernels), and the box / interpolation
+// arithmetic feeds discontinuous decisions (row validity, floor/ceil), so no FMA contraction.
+#include "hp3d_common.h"
+
+namespace {
+
+__device__ __forceinline__ float leaky(float x) { return fmaxf(x, HP3D_LEAKY_SLOPE * x); }
+
+// ---------------------------------------------------------------------------------------
+// conv_naive: one thread per output element; HWIO weights as given by the caller.
+// Debug cross-check for conv_mfma (hp3d_set_option conv_impl=naive) -- never a fallback.
+HP3D_KERNEL(256)
+void conv_naive_kernel(const float* x, int B, int H, int W, int Cin, int in_cs, const float* w, const float* bias,
+                       int k, int stride, int Cout, int act, float* out, int out_cs, int Ho, int Wo,
+                       int pad_t, int pad_l) {
+    const long total = (long)B * Ho * Wo * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        long r = i / Cout;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float acc = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * stride - pad_t + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * stride - pad_l + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float* xp = x + (((size_t)b * H + iy) * W + ix) * in_cs;
+                const float* wp = w + ((size_t)(ky * k + kx) * Cin) * Cout + co;
+                for (int c = 0; c < Cin; ++c) acc = fmaf(xp[c], wp[(size_t)c * Cout], acc);
+            }
+        }
+        acc += bias[co];
+        if (act) acc = leaky(acc);
+        out[(((size_t)b * Ho + oy) * Wo + ox) * out_cs + co] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// im2col3x3: image [B,H,W,3] -> [B,H,W,32] with channel (r*3+s)*3+c = img[y+r-1][x+s-1][c]
+// (zero outside, channels 27..31 zero).  conv1_1 (Cin=3) then runs as a 1x1 MFMA conv with K=32.
+HP3D_KERNEL(256)
+void im2col3x3_kernel(const float* img, int B, int H, int W, float* out) {
+    const long total = (long)B * H * W * 32;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int kk = (int)(i & 31);
+        long r = i >> 5;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        float v = 0.f;
+        if (kk < 27) {
+            const int tap = kk / 3, c = kk - tap * 3;
+            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * H + iy) * W + ix) * 3 + c];
+        }
+        out[i] = v;
+    }
+}
+
+// 2x2/2 VALID max-pool (utils/general.py:61-65), standalone (the pipeline uses the fused epilogue)
+HP3D_KERNEL(256)
+void maxpool2_kernel(const float* x, int B, int H, int W, int C, int in_cs, float* out) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float* p = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * in_cs + c;
+        const float m0 = fmaxf(p[0], p[in_cs]);
+        const float m1 = fmaxf(p[(size_t)W * in_cs], p[(size_t)W * in_cs + in_cs]);
+        out[i] = fmaxf(m0, m1);
+    }
+}
+
+// 8x8/8 average pool on sizes divisible by 8 (nets/PosePriorNetwork.py:61); row-major f32 sum
+HP3D_KERNEL(256)
+void avgpool8_kernel(const float* x, int B, int H, int W, int C, float* out, int out_cs) {
+    const int Ho = H / 8, Wo = W / 8;
+    const long total = (long)B * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % Wo); r /= Wo;
+        const int oy = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        float s = 0.f;
+        for (int dy = 0; dy < 8; ++dy)
+            for (int dx = 0; dx < 8; ++dx)
+                s += x[(((size_t)b * H + oy * 8 + dy) * W + ox * 8 + dx) * C + c];
+        out[(((size_t)b * Ho + oy) * Wo + ox) * out_cs + c] = s / 64.f;
+    }
+}
+
+// TF 1.3 ResizeBilinear, align_corners=False
+__device__ __forceinline__ void resize_coord(int o, float scale, int in_n, int& lo, int& hi, float& t) {
+    const float src = (float)o * scale;
+    lo = (int)floorf(src);
+    hi = min(lo + 1, in_n - 1);
+    t = src - (float)lo;
+}
+
+HP3D_KERNEL(256)
+void resize_bilinear_kernel(const float* x, int B, int H, int W, int C, int in_cs, int oh, int ow, float* out) {
+    const float hscale = (float)H / (float)oh, wscale = (float)W / (float)ow;
+    const long total = (long)B * oh * ow * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long r = i / C;
+        const int ox = (int)(r % ow); r /= ow;
+        const int oy = (int)(r % oh);
+        const int b = (int)(r / oh);
+        int y0, y1, x0, x1; float ty, tx;
+        resize_coord(oy, hscale, H, y0, y1, ty);
+        resize_coord(ox, wscale, W, x0, x1, tx);
+        const float* xb = x + (size_t)b * H * W * in_cs + c;
+        const float tl = xb[((size_t)y0 * W + x0) * in_cs], tr = xb[((size_t)y0 * W + x1) * in_cs];
+        const float bl = xb[((size_t)y1 * W + x0) * in_cs], br = xb[((size_t)y1 * W + x1) * in_cs];
+        const float top = tl + (tr - tl) * tx;
+        const float bot = bl + (br - bl) * tx;
+        out[i] = top + (bot - top) * ty;
+    }
+}
+
+// crop_image_from_xy -> tf.image.crop_and_resize (utils/general.py:163-196, App. B.4)
+HP3D_KERNEL(256)
+void crop_and_resize_kernel(const float* img, int B, int H, int W, int C, const float* center, const float* scale,
+                            int crop, float* out) {
+    const long total = (long)B * crop * crop;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % crop);
+        long r = i / crop;
+        const int y = (int)(r % crop);
+        const int b = (int)(r / crop);
+        // box arithmetic, float32 op by op (utils/general.py:182-190)
+        const float cs = (float)crop / scale[b];
+        const float half = floorf(cs / 2.0f);
+        float y1 = center[b * 2 + 0] - half, y2 = y1 + cs;
+        float x1 = center[b * 2 + 1] - half, x2 = x1 + cs;
+        y1 = y1 / (float)H; y2 = y2 / (float)H; x1 = x1 / (float)W; x2 = x2 / (float)W;
+        const float hs = (crop > 1) ? (y2 - y1) * (float)(H - 1) / (float)(crop - 1) : 0.f;
+        const float ws = (crop > 1) ? (x2 - x1) * (float)(W - 1) / (float)(crop - 1) : 0.f;
+        const float in_y = (crop > 1) ? y1 * (float)(H - 1) + (float)y * hs : 0.5f * (y1 + y2) * (float)(H - 1);
+        const float in_x = (crop > 1) ? x1 * (float)(W - 1) + (float)x * ws : 0.5f * (x1 + x2) * (float)(W - 1);
+        float* o = out + (size_t)i * C;
+        const bool ok = in_y >= 0.f && in_y <= (float)(H - 1) && in_x >= 0.f && in_x <= (float)(W - 1);
+        if (!ok) {
+            for (int c = 0; c < C; ++c) o[c] = 0.f;
+            continue;
+        }
+        const int ty0 = (int)floorf(in_y), ty1 = (int)ceilf(in_y);
+        const int tx0 = (int)floorf(in_x), tx1 = (int)ceilf(in_x);
+        const float ly = in_y - (float)ty0, lx = in_x - (float)tx0;
+        const float* ib = img + (size_t)b * H * W * C;
+        for (int c = 0; c < C; ++c) {
+            const float tl = ib[((size_t)ty0 * W + tx0) * C + c], tr = ib[((size_t)ty0 * W + tx1) * C + c];
+            const float bl = ib[((size_t)ty1 * W + tx0) * C + c], br = ib[((size_t)ty1 * W + tx1) * C + c];
+            const float top = tl + (tr - tl) * lx;
+            const float bot = bl + (br - bl) * lx;
+            o[c] = top + (bot - top) * ly;
+        }
+    }
+}
+
+HP3D_KERNEL(256)
+void copy_channels_kernel(const float* in, long npix, int C, int in_cs, float* out, int out_cs) {
+    const long total = npix * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        out[p * out_cs + c] = in[p * in_cs + c];
+    }
+}
+
+// [npix, C] -> [npix, out_cs] zero padded
+HP3D_KERNEL(256)
+void pad_channels_kernel(const float* in, long npix, int C, float* out, int out_cs) {
+    const long total = npix * out_cs;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % out_cs);
+        const long p = i / out_cs;
+        out[i] = (c < C) ? in[p * C + c] : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Segmentation post-processing (utils/general.py:233-245): 2-class softmax in float32 with a
+// correctly rounded exp (oracle/tf_ops.py:exp_f32_cr), detmap = round-half-even(fg), and the
+// first arg-max of fg over the row-major flattened map as a 64-bit key
+//    key = fg_bits << 32 | (0xFFFFFFFF - flat_index)       (fg >= 0 so its bits order like uints)
+__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const unsigned long long o = __shfl_xor(k, off);
+        k = (o > k) ? o : k;
+    }
+    return k;
+}
+
+__device__ __forceinline__ void softmax_det_key(float l0, float l1, unsigned idx, float& fg, unsigned char& det,
+                                                unsigned long long& key) {
+    const float m = fmaxf(l0, l1);
+    const float e0 = exp_cr(l0 - m), e1 = exp_cr(l1 - m);
+    const float s = e0 + e1;
+    fg = e1 / s;
+    det = (unsigned char)(rintf(fg) == 1.0f);
+    key = ((unsigned long long)__float_as_uint(fg) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+
+// small [B,hs,ws,cs] (channels 0,1) --x8 legacy bilinear--> hand_scoremap [B,H,W,2] (+ det, key)
+HP3D_KERNEL(256)
+void seg_upsample_softmax_kernel(const float* small, int B, int hs, int ws, int cs, int H, int W,
+                                 float* large, unsigned char* det, float* fgout, unsigned long long* keys) {
+    const int b = blockIdx.y;
+    const float hscale = (float)hs / (float)H, wscale = (float)ws / (float)W;
+    const int npx = H * W;
+    unsigned long long best = 0ull;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const int oy = i / W, ox = i - oy * W;
+        int y0, y1, x0, x1; float ty, tx;
+        resize_coord(oy, hscale, hs, y0, y1, ty);
+        resize_coord(ox, wscale, ws, x0, x1, tx);
+        const float* sb = small + (size_t)b * hs * ws * cs;
+        float l[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float tl = sb[((size_t)y0 * ws + x0) * cs + c], tr = sb[((size_t)y0 * ws + x1) * cs + c];
+            const float bl = sb[((size_t)y1 * ws + x0) * cs + c], br = sb[((size_t)y1 * ws + x1) * cs + c];
+            const float top = tl + (tr - tl) * tx;
+            const float bot = bl + (br - bl) * tx;
+            l[c] = top + (bot - top) * ty;
+        }
+        const size_t o = (size_t)b * npx + i;
+        if (large) { large[o * 2] = l[0]; large[o * 2 + 1] = l[1]; }
+        float fg; unsigned char d; unsigned long long key;
+        softmax_det_key(l[0], l[1], (unsigned)i, fg, d, key);
+        det[o] = d;
+        if (fgout) fgout[o] = fg;
+        best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) atomicMax(&keys[b], best);
+}
+
+HP3D_KERNEL(256)
+void seg_softmax_kernel(const float* large, int B, int H, int W, unsigned char* det, float* fgout,
+                        unsigned long long* keys) {
+    const int b = blockIdx.y;
+    const int npx = H * W;
+    unsigned long long best = 0ull;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * npx + i;
+        float fg; unsigned char d; unsigned long long key;
+        softmax_det_key(large[o * 2], large[o * 2 + 1], (unsigned)i, fg, d, key);
+        det[o] = d;
+        if (fgout) fgout[o] = fg;
+        best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) atomicMax(&keys[b], best);
+}
+
+// ---------------------------------------------------------------------------------------
+// Seeded geodesic growth + bounding box (utils/general.py:247-328), one workgroup per image.
+// O_0 = {seed};  O_{j+1} = det AND dilate21x21(O_j), j < max(H,W)//10 passes, bit-packed in LDS;
+// stops early at a fix-point (exactly equivalent: the iteration is deterministic).
+// Row r of the bitmap is WW = ceil(W/32) words; pixel x is bit x%32 of word x/32.
+HP3D_KERNEL(1024)
+void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, int H, int W, int empty_fltmax,
+                      float* mask_out, float* center, float* crop_size, float* scale, int* seed_out) {
+    HP3D_DYN_SMEM(smem_f);
+    unsigned* detb = (unsigned*)smem_f;
+    const int WW = (W + 31) >> 5;
+    const int NWORD = H * WW;
+    unsigned* obj = detb + NWORD;
+    unsigned* tmp = obj + NWORD;
+    __shared__ int s_changed, s_rmin, s_rmax, s_cmin, s_cmax;
+
+    const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
+    const unsigned char* d = det + (size_t)b * H * W;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(keys[b] & 0xFFFFFFFFull);
+    const int sy = (int)(idx / (unsigned)W), sx = (int)(idx % (unsigned)W);
+
+    for (int w = tid; w < NWORD; w += nthr) {
+        const int y = w / WW, wx = w - y * WW;
+        unsigned bits = 0;
+        for (int k = 0; k < 32; ++k) {
+            const int x = wx * 32 + k;
+            if (x < W && d[(size_t)y * W + x]) bits |= (1u << k);
+        }
+        detb[w] = bits;
+        obj[w] = (y == sy && wx == (sx >> 5)) ? (1u << (sx & 31)) : 0u;
+    }
+    if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_cmin = 0x7fffffff; s_cmax = -1; }
+    __syncthreads();
+
+    const int num_passes = max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
+    for (int pass = 0; pass < num_passes; ++pass) {
+        if (tid == 0) s_changed = 0;
+        // horizontal dilation, radius 10
+        for (int w = tid; w < NWORD; w += nthr) {
+            const int wx = w % WW;
+            const unsigned long long lo = wx > 0 ? obj[w - 1] : 0u;
+            const unsigned long long mid = obj[w];
+            const unsigned long long hi = wx + 1 < WW ? obj[w + 1] : 0u;
+            unsigned long long win = (mid << 16) | (lo >> 16) | (hi << 48);
+            win = win | (win << 1) | (win >> 1);     // radius 1
+            win = win | (win << 2) | (win >> 2);     // radius 3
+            win = win | (win << 4) | (win >> 4);     // radius 7
+            win = win | (win << 3) | (win >> 3);     // radius 10
+            tmp[w] = (unsigned)(win >> 16);
+        }
+        __syncthreads();
+        // vertical dilation, radius 10, AND det
+        int changed = 0;
+        for (int w = tid; w < NWORD; w += nthr) {
+            const int y = w / WW;
+            const int ya = max(y - 10, 0), yb = min(y + 10, H - 1);
+            unsigned acc = 0;
+            for (int yy = ya; yy <= yb; ++yy) acc |= tmp[w + (yy - y) * WW];
+            acc &= detb[w];
+            if (acc != obj[w]) changed = 1;
+            // obj is only read through tmp in this phase -> safe to update in place
+            obj[w] = acc;
+        }
+        if (changed) s_changed = 1;
+        __syncthreads();
+        const int any = s_changed;
+        __syncthreads();
+        if (!any) break;
+    }
+
+    // bounding box (calc_center_bb): "x" = row index, "y" = column index
+    int rmin = 0x7fffffff, rmax = -1, cmin = 0x7fffffff, cmax = -1;
+    for (int w = tid; w < NWORD; w += nthr) {
+        const unsigned v = obj[w];
+        if (v) {
+            const int y = w / WW, wx = w - y * WW;
+            rmin = min(rmin, y); rmax = max(rmax, y);
+            cmin = min(cmin, wx * 32 + (__ffs(v) - 1));
+            cmax = max(cmax, wx * 32 + (31 - __clz(v)));
+        }
+    }
+    if (rmax >= 0) {
+        atomicMin(&s_rmin, rmin); atomicMax(&s_rmax, rmax);
+        atomicMin(&s_cmin, cmin); atomicMax(&s_cmax, cmax);
+    }
+    __syncthreads();
+    if (mask_out) {
+        float* mo = mask_out + (size_t)b * H * W;
+        for (int i = tid; i < H * W; i += nthr) {
+            const int y = i / W, x = i - y * W;
+            mo[i] = (obj[y * WW + (x >> 5)] >> (x & 31)) & 1u ? 1.f : 0.f;
+        }
+    }
+    if (tid == 0) {
+        float cx, cy, sz;
+        if (s_rmax >= 0) {
+            const float xmin = (float)s_rmin, xmax = (float)s_rmax, ymin = (float)s_cmin, ymax = (float)s_cmax;
+            cx = 0.5f * (xmax + xmin);
+            cy = 0.5f * (ymax + ymin);
+            sz = fmaxf(xmax - xmin, ymax - ymin);
+        } else if (empty_fltmax) {   // Eigen-3.3 identities: centre finite (0,0), size -inf -> 100
+            cx = 0.f; cy = 0.f; sz = 100.f;
+        } else {                     // +-inf identities: NaN centre -> (160,160); size -> 100
+            cx = 160.f; cy = 160.f; sz = 100.f;
+        }
+        center[b * 2 + 0] = cx;
+        center[b * 2 + 1] = cy;
+        if (crop_size) crop_size[b] = sz;
+        const float best = sz * 1.25f;                       // nets/ColorHandPose3DNetwork.py:84
+        scale[b] = fminf(fmaxf(256.0f / best, 0.25f), 5.0f);  // :85
+        if (seed_out) { seed_out[b * 2] = sy; seed_out[b * 2 + 1] = sx; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fully connected: out[b][o] = sum_i x[b][i] * W[i][o] + bias[o]  (utils/general.py:112-136)
+// workgroup = 64 outputs x 4 K-slices, 8 batch rows per pass; W rows are read coalesced.
+constexpr int FC_BB = 8;
+HP3D_KERNEL(256)
+void fc_kernel(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout, int act,
+               float* out, int out_stride) {
+    __shared__ float red[4][FC_BB][64];
+    const int o = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int ks = threadIdx.x >> 6;
+    const int b0 = blockIdx.y * FC_BB;
+    float acc[FC_BB];
+#pragma unroll
+    for (int j = 0; j < FC_BB; ++j) acc[j] = 0.f;
+    if (o < Cout) {
+        for (int i = ks; i < Cin; i += 4) {
+            const float wv = w[(size_t)i * Cout + o];
+#pragma unroll
+            for (int j = 0; j < FC_BB; ++j) {
+                const int b = b0 + j;
+                const float xv = (b < B) ? x[(size_t)b * x_stride + i] : 0.f;
+                acc[j] = fmaf(xv, wv, acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < FC_BB; ++j) red[ks][j][threadIdx.x & 63] = acc[j];
+    __syncthreads();
+    if (ks == 0 && o < Cout) {
+#pragma unroll
+        for (int j = 0; j < FC_BB; ++j) {
+            const int b = b0 + j;
+            if (b >= B) break;
+            float v = ((red[0][j][threadIdx.x] + red[1][j][threadIdx.x]) + (red[2][j][threadIdx.x] + red[3][j][threadIdx.x])) + bias[o];
+            if (act) v = leaky(v);
+            out[(size_t)b * out_stride + o] = v;
+        }
+    }
+}
+
+// out[b] = concat(feat[b, 0:F], hand_side[b, 0:2])   (nets/ColorHandPose3DNetwork.py:262-263,297-298)
+HP3D_KERNEL(256)
+void concat_handside_kernel(const float* feat, int B, int F, const float* hand_side, float* out) {
+    const long total = (long)B * (F + 2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (F + 2));
+        const long b = i / (F + 2);
+        out[i] = (c < F) ? feat[b * F + c] : hand_side[b * 2 + (c - F)];
+    }
+}
+
+// _get_rot_mat + _flip_right_hand + matmul (nets/ColorHandPose3DNetwork.py:240-245,311-334)
+HP3D_KERNEL(64)
+void lift_epilogue_kernel(const float* u, const float* can, const float* hand_side, int B, float* rot,
+                          float* rel, int do_rot) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (do_rot) {
+        const float ux_b = u[b * 3], uy_b = u[b * 3 + 1], uz_b = u[b * 3 + 2];
+        const float un = sqrtf(((ux_b * ux_b + uy_b * uy_b) + uz_b * uz_b) + 1e-8f);
+        const float st = sinf(un), ct = cosf(un), oc = 1.0f - ct;
+        const float nf = 1.0f / un;
+        const float ux = ux_b * nf, uy = uy_b * nf, uz = uz_b * nf;
+        R[0] = ct + ux * ux * oc; R[1] = ux * uy * oc - uz * st; R[2] = ux * uz * oc + uy * st;
+        R[3] = uy * ux * oc + uz * st; R[4] = ct + uy * uy * oc; R[5] = uy * uz * oc - ux * st;
+        R[6] = uz * ux * oc - uy * st; R[7] = uz * uy * oc + ux * st; R[8] = ct + uz * uz * oc;
+        if (rot) for (int i = 0; i < 9; ++i) rot[b * 9 + i] = R[i];
+    }
+    const bool right = do_rot && (hand_side[b * 2 + 1] > hand_side[b * 2]);   // argmax(hand_side)==1
+    for (int k = 0; k < 21; ++k) {
+        const float x = can[b * 63 + k * 3], y = can[b * 63 + k * 3 + 1];
+        const float z = right ? -can[b * 63 + k * 3 + 2] : can[b * 63 + k * 3 + 2];
+        for (int j = 0; j < 3; ++j) rel[b * 63 + k * 3 + j] = (x * R[j] + y * R[3 + j]) + z * R[6 + j];
+    }
+}
+
+// detect_keypoints (utils/general.py:331-344): first arg-max per channel; one workgroup per (b,c)
+__device__ __forceinline__ unsigned ord_f32(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+HP3D_KERNEL(256)
+void argmax2d_kernel(const float* x, int H, int W, int C, int cs, int* out_rc) {
+    __shared__ unsigned long long red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* xb = x + (size_t)b * H * W * cs + c;
+    unsigned long long best = 0ull;
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+        const unsigned long long key = ((unsigned long long)ord_f32(xb[(size_t)i * cs]) << 32) |
+                                       (unsigned long long)(0xFFFFFFFFu - (unsigned)i);
+        best = key > best ? key : best;
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = red[i] > best ? red[i] : best;
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+        out_rc[((size_t)b * C + c) * 2] = (int)(idx / (unsigned)W);
+        out_rc[((size_t)b * C + c) * 2 + 1] = (int)(idx % (unsigned)W);
+    }
+}
+
+inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
+    long g = (total + block - 1) / block;
+    if (g < 1) g = 1;
+    return (int)(g > cap ? cap : g);
+}
+
+}  // namespace
+
+// ---- launchers ---------------------------------------------------------------------------
+void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, const float* w, const float* bias,
+                       int k, int stride, int Cout, int act, float* out, int out_cs, int Ho, int Wo, int pad_t,
+                       int pad_l, hipStream_t s) {
+    HP3D_LAUNCH(conv_naive_kernel, dim3(grid_for((long)B * Ho * Wo * Cout)), dim3(256), 0, s, x, B, H, W, Cin, in_cs,
+                w, bias, k, stride, Cout, act, out, out_cs, Ho, Wo, pad_t, pad_l);
+}
+void im2col3x3_launch(const float* img, int B, int H, int W, float* out32, hipStream_t s) {
+    HP3D_LAUNCH(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 32)), dim3(256), 0, s, img, B, H, W, out32);
+}
+void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, float* out, hipStream_t s) {
+    HP3D_LAUNCH(maxpool2_kernel, dim3(grid_for((long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, s, x, B, H, W, C,
+                in_cs, out);
+}
+void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int out_cs, hipStream_t s) {
+    HP3D_LAUNCH(avgpool8_kernel, dim3(grid_for((long)B * (H / 8) * (W / 8) * C)), dim3(256), 0, s, x, B, H, W, C,
+                out, out_cs);
+}
+void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs, int oh, int ow, float* out,
+                            hipStream_t s) {
+    HP3D_LAUNCH(resize_bilinear_kernel, dim3(grid_for((long)B * oh * ow * C)), dim3(256), 0, s, x, B, H, W, C, in_cs,
+                oh, ow, out);
+}
+void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const float* center, const float* scale,
+                            int crop, float* out, hipStream_t s) {
+    HP3D_LAUNCH(crop_and_resize_kernel, dim3(grid_for((long)B * crop * crop)), dim3(256), 0, s, img, B, H, W, C,
+                center, scale, crop, out);
+}
+void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s) {
+    HP3D_LAUNCH(copy_channels_kernel, dim3(grid_for((long)npix * C)), dim3(256), 0, s, in, (long)npix, C, in_cs, out,
+                out_cs);
+}
+void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s) {
+    HP3D_LAUNCH(pad_channels_kernel, dim3(grid_for((long)npix * out_cs)), dim3(256), 0, s, in, (long)npix, C, out,
+                out_cs);
+}
+void seg_upsample_softmax_launch(const float* small, int B, int hs, int ws, int cs, int H, int W,
+                                 float* scoremap_large, const MaskBuffers& mb, hipStream_t s) {
+    (void)hipMemsetAsync(mb.argmax_key, 0, sizeof(unsigned long long) * B, s);
+    const int gx = grid_for((long)H * W, 256, 64);
+    HP3D_LAUNCH(seg_upsample_softmax_kernel, dim3(gx, B), dim3(256), 0, s, small, B, hs, ws, cs, H, W, scoremap_large,
+                mb.det, mb.fg, mb.argmax_key);
+}
+void seg_softmax_launch(const float* scoremap_large, int B, int H, int W, const MaskBuffers& mb, hipStream_t s) {
+    (void)hipMemsetAsync(mb.argmax_key, 0, sizeof(unsigned long long) * B, s);
+    const int gx = grid_for((long)H * W, 256, 64);
+    HP3D_LAUNCH(seg_softmax_kernel, dim3(gx, B), dim3(256), 0, s, scoremap_large, B, H, W, mb.det, mb.fg,
+                mb.argmax_key);
+}
+void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltmax, float* mask_out, float* center,
+                      float* crop_size, float* scale, int* seed, hipStream_t s) {
+    const int WW = (W + 31) / 32;
+    const size_t smem = (size_t)3 * H * WW * sizeof(unsigned);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)mask_grow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+        attr_done = true;
+    }
+    HP3D_LAUNCH(mask_grow_kernel, dim3(B), dim3(1024), smem, s, (const unsigned char*)mb.det,
+                (const unsigned long long*)mb.argmax_key, H, W, empty_fltmax, mask_out, center, crop_size, scale, seed);
+}
+void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout, int act,
+               float* out, int out_stride, hipStream_t s) {
+    HP3D_LAUNCH(fc_kernel, dim3((Cout + 63) / 64, (B + FC_BB - 1) / FC_BB), dim3(256), 0, s, x, B, Cin, x_stride, w,
+                bias, Cout, act, out, out_stride);
+}
+void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s) {
+    HP3D_LAUNCH(concat_handside_kernel, dim3(grid_for((long)B * (F + 2))), dim3(256), 0, s, feat, B, F, hand_side, out);
+}
+void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B, float* rot,
+                          float* coord_rel, int do_flip_rot, hipStream_t s) {
+    HP3D_LAUNCH(lift_epilogue_kernel, dim3((B + 63) / 64), dim3(64), 0, s, u, coord_can, hand_side, B, rot, coord_rel,
+                do_flip_rot);
+}
+void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s) {
+    HP3D_LAUNCH(argmax2d_kernel, dim3(C, B), dim3(256), 0, s, x, H, W, C, cs, out_rc);
+}

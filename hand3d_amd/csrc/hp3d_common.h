@@ -1,0 +1,89 @@
+// hp3d_common.h -- shared declarations of the gfx950 engine (kernels + executor).
+//
+// Two build modes:
+//   * default          : hipcc --offload-arch=gfx950 (the product, libhp3d.so)
+//   * -DHP3D_EMU       : g++ with tests/emu/hp3d_emu.h -- a fiber-per-lane CPU interpreter of the
+//                        same kernel sources, used ONLY by the CPU test-suite to check index math
+//                        (tile maps, weight packing, masks) without a GPU.  Never shipped.
+#pragma once
+
+#ifdef HP3D_EMU
+#include "hp3d_emu.h"
+#else
+#include <hip/hip_runtime.h>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define HP3D_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
+#define HP3D_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
+#define HP3D_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
+#endif
+
+#include <stdint.h>
+
+#define HP3D_LEAKY_SLOPE 0.01f
+
+// ---------------------------------------------------------------------------------------
+// MFMA implicit-GEMM convolution (conv_mfma.hip).  NHWC float32, channel-padded to 32.
+struct ConvParams {
+    const float* in;      // [B,H,W,in_cs]; the Cin (multiple of 32) channels start at `in`
+    const float* wpk;     // packed weights [tap][Cin/8][Cout/32][h:2][n:32][j:4]
+    const float* bias;    // [Cout] (padded couts: 0)
+    float* out;           // [B,Ho',Wo',out_cs] (Ho',Wo' halved when pooling); channel 0 at `out`
+    int B, H, W;          // input extent
+    int Ho, Wo;           // conv output extent (before the fused 2x2 max-pool)
+    int Cin, in_cs;       // iterated channels (multiple of 32), input channel stride
+    int Cout, out_cs;     // padded couts (multiple of 32), output channel stride
+    int cout_store;       // couts actually written (<= Cout)
+    int pad_t, pad_l;     // TF SAME "before" padding
+    int tiles_x, tiles_y; // spatial tiles per image
+    int act;              // HP3D_ACT_*
+};
+
+// ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------
+struct ConvPlan {      // chosen by conv_mfma_plan() from the layer geometry
+    int th, tw, bn;    // spatial tile (output pixels) and cout tile
+    int variant;       // index into the instantiation table
+};
+int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cout, int pool, int B, ConvPlan* plan);
+int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s);
+const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan);
+
+// debug cross-check (one thread per output element, obviously-correct loops)
+void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, const float* w_hwio_like,
+                       const float* bias, int k, int stride, int Cout, int act, float* out, int out_cs,
+                       int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
+
+void im2col3x3_launch(const float* img, int B, int H, int W, float* out32, hipStream_t s);
+void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, float* out, hipStream_t s);
+void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int out_cs, hipStream_t s);
+void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs,
+                            int oh, int ow, float* out, hipStream_t s);
+void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const float* center,
+                            const float* scale, int crop, float* out, hipStream_t s);
+
+struct MaskBuffers {           // per-call scratch owned by the executor
+    unsigned long long* argmax_key;  // [B]
+    unsigned char* det;              // [B,H,W]
+    float* fg;                       // [B,H,W] (optional output for tests; may be null)
+};
+// seg logits (small map, channel stride cs) -> hand_scoremap [B,H,W,2], det bytes, arg-max keys
+void seg_upsample_softmax_launch(const float* small, int B, int hs, int ws, int cs, int H, int W,
+                                 float* scoremap_large, const MaskBuffers& mb, hipStream_t s);
+// same from an already-large scoremap [B,H,W,2] (hp3d_mask_from_scoremap)
+void seg_softmax_launch(const float* scoremap_large, int B, int H, int W, const MaskBuffers& mb, hipStream_t s);
+// geodesic growth + bbox + centre / crop size / scale.  mask_out (float [B,H,W]) may be null.
+void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltmax, float* mask_out,
+                      float* center, float* crop_size, float* scale, int* seed, hipStream_t s);
+
+void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout,
+               int act, float* out, int out_stride, hipStream_t s);
+// [B,4096|2048 feats] + hand_side concat is handled by the executor (copies 2 floats per row)
+void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s);
+// u = (ux,uy,uz) [B,3], coord_can [B,63], hand_side [B,2] -> rot [B,9], coord_rel [B,63]
+void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B,
+                          float* rot, float* coord_rel, int do_flip_rot, hipStream_t s);
+void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s);
+void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s);
+void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s);

@@ -1,0 +1,154 @@
+/*
+ * hp3d.h -- C-ABI of libhp3d.so: the MI355X (gfx950) engine behind the Python call
+ * surface of lmb-freiburg/hand3d's ColorHandPose3DNetwork / PosePriorNetwork.
+ *
+ * The reference has no FFI of its own: its "operator API" is the method surface of two
+ * Python classes whose arithmetic runs inside TensorFlow 1.3.  Each entry
+ * point below names the reference interface it replaces (file:line relative to the
+ * reference tree).  The reference-side binding (ctypes) is hand3d_amd/_lib.py and is
+ * reproduced in INTEGRATION.md.
+ *
+ * Conventions
+ *   - return 0 on success, a negative hp3d_status otherwise; hp3d_last_error() gives text;
+ *   - no C++ exception crosses this boundary, no torch/TF types appear in it;
+ *   - all tensors are float32, NHWC, contiguous (the reference's layout: utils/general.py:40-46);
+ *   - "host" entry points take caller-owned host buffers, are synchronous and never retain
+ *     a pointer; "_dev" entry points take device pointers (hipMalloc'd by anyone in this
+ *     process, e.g. a torch tensor's data_ptr) and are stream-ordered on hp3d_stream(ctx):
+ *     call hp3d_sync() before reading results;
+ *   - any output pointer may be NULL (that output is then not copied out);
+ *   - a context is thread-compatible: no concurrent calls on one context.
+ */
+#ifndef HP3D_H
+#define HP3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hp3d_ctx hp3d_ctx;
+
+typedef enum {
+    HP3D_OK = 0,
+    HP3D_ERR_ARG = -1,        /* bad argument / shape (the reference's bare asserts)            */
+    HP3D_ERR_HIP = -2,        /* a HIP runtime call failed                                      */
+    HP3D_ERR_WEIGHTS = -3,    /* missing / mis-shaped variable at finalize, or not finalized    */
+    HP3D_ERR_UNSUPPORTED = -4,/* e.g. variant 'local' (SURVEY.md 8f N3), evaluation=False       */
+    HP3D_ERR_NOMEM = -5
+} hp3d_status;
+
+/* PosePriorNetwork variants -- nets/PosePriorNetwork.py:59-95 */
+enum { HP3D_VARIANT_DIRECT = 0, HP3D_VARIANT_BOTTLENECK = 1, HP3D_VARIANT_PROPOSED = 2 };
+/* activation fused behind a conv / fc -- utils/general.py:55-59,132-136 */
+enum { HP3D_ACT_NONE = 0, HP3D_ACT_LEAKY = 1 };
+
+int hp3d_abi_version(void);
+
+/* ---- context ----------------------------------------------------------------------------
+ * replaces: tf.Session(config=...) + graph construction (run.py:44-50).                     */
+int hp3d_create(int device, hp3d_ctx** out);
+int hp3d_destroy(hp3d_ctx* ctx);
+const char* hp3d_last_error(hp3d_ctx* ctx);          /* ctx may be NULL: last global error   */
+void* hp3d_stream(hp3d_ctx* ctx);                    /* the hipStream_t all work is queued on */
+int hp3d_sync(hp3d_ctx* ctx);
+/* options: "empty_reduce" = "inf" | "fltmax" (oracle/general.py EMPTY_REDUCE);
+ *          "conv_impl"    = "mfma" | "naive" (debug cross-check kernel, never a fallback).   */
+int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value);
+
+/* ---- weights ----------------------------------------------------------------------------
+ * replaces: ColorHandPose3DNetwork.init / PosePriorNetwork.init, i.e. pickle dict ->
+ * tf.contrib.framework.assign_from_values (nets/ColorHandPose3DNetwork.py:34-59,
+ * nets/PosePriorNetwork.py:36-57).  `tf_var_name` is the pickle key, e.g.
+ * "PoseNet2D/conv6_1/weights"; conv weights HWIO [k,k,Cin,Cout], FC weights [in,out],
+ * biases [out] (utils/general.py:41-50,117-126).  Data is copied; unknown names are
+ * rejected (HP3D_ERR_ARG), mis-shaped ones too.                                              */
+int hp3d_set_weight(hp3d_ctx* ctx, const char* tf_var_name, const float* data,
+                    const int64_t* shape, int rank);
+/* Pack everything set so far for the device (repack HWIO -> MFMA fragment order, permute
+ * the concat channels of conv6_1/conv7_1, upload).  Nets whose variables are all present
+ * become runnable; a net with only some of its variables is an error.  dtype: 0 = f32.      */
+int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype);
+/* The packed device blob (identical layout on every rank): size, export to / import from a
+ * device buffer.  Used for the one-off RCCL broadcast of weights (bench.py, N>1).           */
+int hp3d_weights_blob_bytes(hp3d_ctx* ctx, size_t* bytes);
+int hp3d_weights_blob_export(hp3d_ctx* ctx, void* dev_dst);
+int hp3d_weights_blob_import(hp3d_ctx* ctx, const void* dev_src, int nets_mask);
+int hp3d_nets_mask(hp3d_ctx* ctx);   /* bit0 HandSegNet, bit1 PoseNet2D, bit2 PosePrior, bit3 ViewpointNet, bit4 bottleneck */
+
+/* ---- whole-path entry points ------------------------------------------------------------
+ * hp3d_infer_full   replaces ColorHandPose3DNetwork.inference (nets/ColorHandPose3DNetwork.py:61-99)
+ *   image [B,H,W,3] (x/255-0.5 done by the caller, run.py:59), hand_side [B,2] one-hot ->
+ *   hand_scoremap [B,H,W,2], image_crop [B,256,256,3], scale_crop [B,1], center [B,2] (row,col),
+ *   keypoints_scoremap [B,256,256,21], keypoint_coord3d [B,21,3].  H, W multiples of 8.
+ * hp3d_infer_2d     replaces .inference2d (:101-129): keypoints_scoremap, image_crop, scale_crop, center.
+ * hp3d_handsegnet   replaces .inference_detection (:131-168): scoremap_large [B,H,W,2]
+ *   (scoremap_small [B,H/8,W/8,2] is the pre-upsampling map, for staged parity tests).
+ * hp3d_posenet2d    replaces .inference_pose2d (:170-219): the 3 scoremaps [B,h/8,w/8,21].
+ * hp3d_poseprior    replaces PosePriorNetwork(variant).inference (nets/PosePriorNetwork.py:59-95):
+ *   scoremap256 [B,256,256,21] -> coord_xyz_rel_normed [B,21,3], coord3d [B,21,3], R [B,3,3]
+ *   (R untouched for direct/bottleneck, where the reference returns None).
+ * hp3d_pose3d       replaces ._inference_pose3d (:221-247) on a [B,32,32,21] scoremap.
+ * hand_mask (extra, may be NULL): the internal objectmap [B,H,W] of single_obj_scoremap
+ *   (utils/general.py:233-268), exposed so tests can assert mask equality first.            */
+int hp3d_infer_full(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                    float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                    float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask);
+int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                        float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                        float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask);
+int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image,
+                  float* keypoints_scoremap, float* image_crop, float* scale_crop, float* center);
+int hp3d_handsegnet(hp3d_ctx* ctx, int B, int H, int W, const float* image,
+                    float* scoremap_large, float* scoremap_small);
+int hp3d_posenet2d(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop,
+                   float* scoremap0, float* scoremap1, float* scoremap2);
+int hp3d_posenet2d_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop,
+                       float* scoremap0, float* scoremap1, float* scoremap2);
+int hp3d_poseprior(hp3d_ctx* ctx, int B, int variant, const float* scoremap256, const float* hand_side,
+                   float* coord_xyz_rel_normed, float* coord3d, float* rot_mat);
+int hp3d_pose3d(hp3d_ctx* ctx, int B, const float* scoremap32, const float* hand_side,
+                float* coord_xyz_rel_normed, float* coord_can, float* rot_mat);
+
+/* ---- per-op entry points (unit/parity tests; same kernels the pipeline runs) --------------
+ * hp3d_conv2d          NetworkOps.conv/conv_relu (+ max_pool when pool=1): utils/general.py:36-65
+ *                      x [B,H,W,Cin], w HWIO, SAME padding incl. the asymmetric stride-2 case.
+ * hp3d_maxpool2        NetworkOps.max_pool, 2x2/2 VALID                       utils/general.py:61-65
+ * hp3d_avgpool8        tf.nn.avg_pool 8x8/8                                   nets/PosePriorNetwork.py:61
+ * hp3d_resize_bilinear tf.image.resize_images (TF1.3 legacy bilinear)         nets/ColorHandPose3DNetwork.py:97,128,166
+ * hp3d_crop_and_resize crop_image_from_xy -> tf.image.crop_and_resize         utils/general.py:163-196
+ * hp3d_mask_from_scoremap single_obj_scoremap + calc_center_bb + scale        utils/general.py:233-328, CHP3D.py:82-85
+ *                      -> mask [B,H,W], center [B,2], crop_size [B,1] (before *1.25), scale [B,1], seed int32 [B,2]
+ * hp3d_fc              NetworkOps.fully_connected(_relu)                      utils/general.py:112-136
+ * hp3d_argmax2d        detect_keypoints (per-channel first arg-max)           utils/general.py:331-344
+ *                      x [B,H,W,C] -> int32 [B,C,2] (row, col)                                    */
+int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin,
+                const float* w_hwio, const float* bias, int k, int stride, int Cout,
+                int act, int pool, float* out);
+int hp3d_maxpool2(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, float* out);
+int hp3d_avgpool8(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, float* out);
+int hp3d_resize_bilinear(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C,
+                         int out_h, int out_w, float* out);
+int hp3d_crop_and_resize(hp3d_ctx* ctx, const float* image, int B, int H, int W, int C,
+                         const float* center, const float* scale, int crop_size, float* out);
+int hp3d_mask_from_scoremap(hp3d_ctx* ctx, const float* scoremap, int B, int H, int W,
+                            float* mask, float* center, float* crop_size, float* scale, int32_t* seed);
+int hp3d_fc(hp3d_ctx* ctx, const float* x, int B, int Cin, const float* w, const float* bias,
+            int Cout, int act, float* out);
+int hp3d_argmax2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int32_t* out_rc);
+
+/* ---- measurement ------------------------------------------------------------------------
+ * With profiling on, every launch of the last whole-path call is bracketed by hipEvents on
+ * the ctx stream.  hp3d_prof_get(i): layer name, kernel family, ms, algorithmic FLOPs and
+ * algorithmic bytes (input once + weights once + output once).                */
+int hp3d_set_profiling(hp3d_ctx* ctx, int on);
+int hp3d_prof_count(hp3d_ctx* ctx);
+int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, int kernel_cap,
+                  float* ms, double* flops, double* bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HP3D_H */

@@ -1,0 +1,198 @@
+// hp3d_emu.cpp -- fiber scheduler + collectives + HIP runtime stand-ins (see hp3d_emu.h).
+#include "hp3d_emu.h"
+
+#include <chrono>
+#include <vector>
+
+EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu_gridDim;
+float* hp3d_emu_smem = nullptr;
+
+extern "C" void hp3d_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+.text
+.globl hp3d_emu_switch
+.type hp3d_emu_switch,@function
+hp3d_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size hp3d_emu_switch, .-hp3d_emu_switch
+)");
+
+namespace {
+
+constexpr size_t kStack = 96 * 1024;
+
+struct Fiber {
+    void* sp = nullptr;
+    bool done = false;
+    unsigned tid = 0;
+};
+
+struct WaveX {
+    int count = 0, gen = 0;
+    float a[2][64], b[2][64];
+    unsigned long long v[2][64];
+};
+
+struct BlockState {
+    std::vector<Fiber> fibers;
+    std::vector<WaveX> waves;
+    int nthr = 0, alive = 0;
+    int bar_count = 0, bar_gen = 0;
+    const std::function<void()>* body = nullptr;
+    Fiber* cur = nullptr;
+    void* main_sp = nullptr;
+};
+
+BlockState g_blk;
+std::vector<char> g_stacks;
+std::vector<char> g_smem;
+
+void yield_to_main() { hp3d_emu_switch(&g_blk.cur->sp, g_blk.main_sp); }
+
+void release_barrier_if_complete() {
+    if (g_blk.alive > 0 && g_blk.bar_count >= g_blk.alive) {
+        g_blk.bar_count = 0;
+        g_blk.bar_gen++;
+    }
+}
+
+void fiber_entry() {
+    (*g_blk.body)();
+    g_blk.cur->done = true;
+    g_blk.alive--;
+    release_barrier_if_complete();
+    yield_to_main();
+    abort();   // never resumed
+}
+
+// one rendezvous of the (up to) 64 lanes of the calling fiber's wave; returns the slot that was filled
+int wave_rendezvous(WaveX& w, int lanes_in_wave) {
+    const int gen = w.gen;
+    if (++w.count == lanes_in_wave) {
+        w.count = 0;
+        w.gen++;
+    } else {
+        while (w.gen == gen) yield_to_main();
+    }
+    return gen & 1;
+}
+
+}  // namespace
+
+void hp3d_emu_syncthreads() {
+    const int gen = g_blk.bar_gen;
+    g_blk.bar_count++;
+    release_barrier_if_complete();
+    while (g_blk.bar_gen == gen) yield_to_main();
+}
+
+f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c) {
+    const unsigned tid = g_blk.cur->tid;
+    WaveX& w = g_blk.waves[tid >> 6];
+    const int lane = tid & 63, slot = w.gen & 1;
+    w.a[slot][lane] = a;
+    w.b[slot][lane] = b;
+    wave_rendezvous(w, 64);
+    // v_mfma_f32_32x32x2_f32: A[i][k] in lane i+32k, B[k][j] in lane j+32k,
+    // D reg r of lane l: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5); k-ordered fmaf chain.
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float d = c[r];
+        d = fmaf(w.a[slot][row], w.b[slot][col], d);
+        d = fmaf(w.a[slot][row + 32], w.b[slot][col + 32], d);
+        c[r] = d;
+    }
+    return c;
+}
+
+unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask) {
+    const unsigned tid = g_blk.cur->tid;
+    WaveX& w = g_blk.waves[tid >> 6];
+    const int lane = tid & 63, slot = w.gen & 1;
+    w.v[slot][lane] = v;
+    const int lanes = std::min(64, g_blk.nthr - (int)(tid & ~63u));
+    wave_rendezvous(w, lanes);
+    return w.v[slot][(lane ^ mask) & 63];
+}
+
+void hp3d_emu_run(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body) {
+    const int nthr = (int)(block.x * block.y * block.z);
+    if (g_stacks.size() < (size_t)nthr * kStack) g_stacks.resize((size_t)nthr * kStack);
+    if (g_smem.size() < shmem + 64) g_smem.resize(shmem + 64);
+    hp3d_emu_smem = (float*)(((uintptr_t)g_smem.data() + 63) & ~(uintptr_t)63);
+    hp3d_emu_blockDim = {block.x, block.y, block.z};
+    hp3d_emu_gridDim = {grid.x, grid.y, grid.z};
+    g_blk.body = &body;
+    g_blk.nthr = nthr;
+    for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+            for (unsigned bx = 0; bx < grid.x; ++bx) {
+                hp3d_emu_blockIdx = {bx, by, bz};
+                g_blk.fibers.assign(nthr, Fiber());
+                g_blk.waves.assign((nthr + 63) / 64, WaveX());
+                g_blk.alive = nthr;
+                g_blk.bar_count = 0;
+                g_blk.bar_gen = 0;
+                for (int t = 0; t < nthr; ++t) {
+                    char* top = g_stacks.data() + (size_t)(t + 1) * kStack;
+                    top = (char*)((uintptr_t)top & ~(uintptr_t)15);
+                    void** sp = (void**)top;
+                    *--sp = nullptr;                  // fake return address of fiber_entry's "caller"
+                    *--sp = (void*)&fiber_entry;      // `ret` target of the first switch
+                    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+                    g_blk.fibers[t].sp = sp;
+                    g_blk.fibers[t].tid = (unsigned)t;
+                }
+                while (g_blk.alive > 0) {
+                    for (int t = 0; t < nthr; ++t) {
+                        Fiber& f = g_blk.fibers[t];
+                        if (f.done) continue;
+                        g_blk.cur = &f;
+                        hp3d_emu_threadIdx = {(unsigned)t % block.x, ((unsigned)t / block.x) % block.y,
+                                              (unsigned)t / (block.x * block.y)};
+                        hp3d_emu_switch(&g_blk.main_sp, f.sp);
+                    }
+                }
+            }
+}
+
+// ---- HIP runtime stand-ins ---------------------------------------------------------------
+hipError_t hipMalloc(void** p, size_t n) {
+    *p = aligned_alloc(256, (n + 255) / 256 * 256);
+    return *p ? hipSuccess : hipErrorUnknown;
+}
+hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+hipError_t hipStreamCreate(hipStream_t* s) { *s = (void*)1; return hipSuccess; }
+hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new double(0.0); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete (double*)e; return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) {
+    *(double*)e = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(*(double*)b - *(double*)a); return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+hipError_t hipSetDevice(int) { return hipSuccess; }
+hipError_t hipGetLastError() { return hipSuccess; }
+const char* hipGetErrorString(hipError_t) { return "emu"; }
+hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }

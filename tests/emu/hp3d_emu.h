@@ -1,0 +1,86 @@
+// hp3d_emu.h -- CPU interpreter shim for the HIP kernel sources (TEST INFRASTRUCTURE ONLY).
+//
+// Compiling hand3d_amd/csrc/*.hip with `g++ -x c++ -DHP3D_EMU` against this header yields
+// libhp3d_emu.so: the same kernels and the same executor, but every GPU thread is a fiber on one
+// host thread, __syncthreads()/wave collectives are cooperative rendezvous, and
+// v_mfma_f32_32x32x2_f32 is evaluated from its documented lane->element maps as an fmaf chain.
+// It lets `pytest -m "not gpu"` check tile maps, weight packing, halo/zero-fill, masks and the
+// executor's wiring on small shapes without a GPU.  It is never shipped or loaded by the product.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x16 __attribute__((vector_size(64)));
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct EmuIdx { unsigned x, y, z; };
+extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu_gridDim;
+#define threadIdx hp3d_emu_threadIdx
+#define blockIdx hp3d_emu_blockIdx
+#define blockDim hp3d_emu_blockDim
+#define gridDim hp3d_emu_gridDim
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define HP3D_KERNEL(nthr)
+extern float* hp3d_emu_smem;
+#define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem
+
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+void hp3d_emu_run(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& body);
+#define HP3D_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hp3d_emu_run(grid, block, shmem, [=]() { kern(__VA_ARGS__); })
+
+void hp3d_emu_syncthreads();
+#define __syncthreads hp3d_emu_syncthreads
+f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
+#define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))
+unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
+inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }
+
+template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline int __ffs(unsigned v) { return __builtin_ffs((int)v); }
+inline int __clz(unsigned v) { return v ? __builtin_clz(v) : 32; }
+using std::max;
+using std::min;
+
+// ---- minimal HIP runtime (host memory stands in for device memory) ----
+hipError_t hipMalloc(void** p, size_t n);
+hipError_t hipFree(void* p);
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st);
+hipError_t hipStreamCreate(hipStream_t* s);
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
+hipError_t hipGetDeviceCount(int* n);
+hipError_t hipSetDevice(int d);
+hipError_t hipGetLastError();
+const char* hipGetErrorString(hipError_t e);
+hipError_t hipFuncSetAttribute(const void* f, int attr, int v);

@@ -61,6 +61,7 @@ EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None
 _lib_path = None
+_loaded = {}
 
 
 class Hp3dError(RuntimeError):
@@ -75,9 +76,9 @@ def load(path=None):
     """dlopen the engine and attach prototypes.  Raises if the library is absent: there is no
     Python/NumPy fallback for the product path."""
     global _lib, _lib_path
-    path = path or lib_path()
-    if _lib is not None and _lib_path == path:
-        return _lib
+    path = os.path.abspath(path or lib_path())
+    if path in _loaded:
+        return _loaded[path]
     if not os.path.exists(path):
         raise Hp3dError("HIP engine library not found at %s -- build it with `python -m hand3d_amd.build` "
                         "(hipcc, gfx950). The product has no CPU fallback." % path)
@@ -86,6 +87,7 @@ def load(path=None):
         fn = getattr(lib, name)   # AttributeError if include/hp3d.h and the library disagree
         fn.restype = res
         fn.argtypes = args
+    _loaded[path] = lib
     _lib, _lib_path = lib, path
     return lib
 

@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, 'libhp3d.so')
 SOURCES = ['conv_mfma.hip', 'glue.hip', 'engine.hip']
 HEADERS = ['hp3d_common.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
-         '-Wno-unused-function', '-Wno-unused-result']
+         '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
 
 
 def _stale(target, deps):

@@ -505,8 +505,7 @@ int run_poseprior_can(hp3d_ctx* ctx, const float* sm32 /*[B,32,32,32]*/, const f
         CHK(run_conv(ctx, CL(ctx, nm), x, cs, B, h, w, a, ch[i], 0, &h, &w));
         snprintf(nm, sizeof nm, "PosePrior/conv_pose_%d_2", i);
         CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
-        x = b; cs = ch[i];
-        std::swap(a, b);
+        x = b; cs = ch[i];   // next pair: b -> a -> b (no aliasing)
     }
     // x: [B,4,4,128] contiguous == NHWC flatten (h,w,c)
     concat_handside_launch(x, B, 2048, hs, ctx->d_fcin, ctx->stream);
@@ -534,8 +533,7 @@ int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, floa
         CHK(run_conv(ctx, CL(ctx, nm), x, cs, B, h, w, a, ch[i], 0, &h, &w));
         snprintf(nm, sizeof nm, "ViewpointNet/conv_vp_%d_2", i);
         CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
-        x = b; cs = ch[i];
-        std::swap(a, b);
+        x = b; cs = ch[i];   // next pair: b -> a -> b (no aliasing)
     }
     concat_handside_launch(x, B, 4096, hs, ctx->d_fcin, ctx->stream);
     CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp0"), ctx->d_fcin, B, 4098, ctx->d_fc1, 256));
@@ -611,7 +609,7 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
     CHK(need_nets(ctx, NET_SEG | NET_POSE | NET_PRIOR | NET_VP));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, H, W));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     const float* d_img = image;
     const float* d_hs = hand_side;
     if (!dev) {
@@ -644,7 +642,7 @@ int posenet_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop, fl
     CHK(need_nets(ctx, NET_POSE));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, H, W));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     const float* d_img = image_crop;
     if (!dev) {
         CHK(copy_in(ctx, ctx->d_image, image_crop, (size_t)B * H * W * 3, false));
@@ -923,7 +921,7 @@ int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float*
     CHK(need_nets(ctx, NET_SEG | NET_POSE));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, H, W));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
     CHK(run_detect_and_crop(ctx, ctx->d_image, B, H, W, 0));
     CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256));
@@ -945,7 +943,7 @@ int hp3d_handsegnet(hp3d_ctx* ctx, int B, int H, int W, const float* image, floa
     CHK(need_nets(ctx, NET_SEG));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, H, W));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
     CHK(run_handsegnet(ctx, ctx->d_image, B, H, W));
     if (scoremap_large) {
@@ -986,7 +984,7 @@ int hp3d_poseprior(hp3d_ctx* ctx, int B, int variant, const float* scoremap256, 
                        : variant == HP3D_VARIANT_BOTTLENECK ? (NET_PRIOR | NET_BOTTLENECK) : NET_PRIOR));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, 256, 256));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     // stage the [B,256,256,21] GT scoremaps in bufA, pool 8x8 into the padded [B,32,32,32] buffer
     CHK(copy_in(ctx, ctx->bufB, scoremap256, (size_t)B * 256 * 256 * 21, false));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_pooled, 0, sizeof(float) * (size_t)B * 32 * 32 * 32, ctx->stream));
@@ -1002,7 +1000,7 @@ int hp3d_pose3d(hp3d_ctx* ctx, int B, const float* scoremap32, const float* hand
     CHK(need_nets(ctx, NET_PRIOR | NET_VP));
     HIPCHK(ctx, hipSetDevice(ctx->device));
     CHK(ensure_arena(ctx, B, 256, 256));
-    prof_reset(ctx);
+    if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     CHK(copy_in(ctx, ctx->bufB, scoremap32, (size_t)B * 32 * 32 * 21, false));
     pad_channels_launch(ctx->bufB, B * 32 * 32, 21, ctx->d_pooled, 32, ctx->stream);
     return lift_common(ctx, B, HP3D_VARIANT_PROPOSED, ctx->d_pooled, hand_side, coord_xyz_rel_normed, coord_can, rot_mat);
@@ -1174,8 +1172,8 @@ int hp3d_argmax2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int
 // ---- measurement ---------------------------------------------------------------------------------
 int hp3d_set_profiling(hp3d_ctx* ctx, int on) {
     if (!ctx) return HP3D_ERR_ARG;
-    ctx->profiling = on ? 1 : 0;
-    if (!on) prof_reset(ctx);
+    if (on != ctx->profiling) prof_reset(ctx);
+    ctx->profiling = (on == 2) ? 2 : (on ? 1 : 0);
     return 0;
 }
 int hp3d_prof_count(hp3d_ctx* ctx) { return ctx ? (int)ctx->prof.size() : 0; }

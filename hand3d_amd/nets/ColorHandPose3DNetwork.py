@@ -1,0 +1,94 @@
+"""ColorHandPose3DNetwork -- the reference's call surface on the MI355X engine.
+
+Mirrors nets/ColorHandPose3DNetwork.py:28-99,101-219 of lmb-freiburg/hand3d: same method
+names, argument order, return-tuple order, NHWC float32 shapes.  Where the reference built
+TF-graph tensors to be evaluated later by `sess.run`, these methods evaluate eagerly on NumPy
+arrays through libhp3d.so (hand-written HIP, gfx950).  There is no TensorFlow, no torch and no
+CPU fallback behind them.
+
+A script written against the reference changes three lines:
+    net = ColorHandPose3DNetwork()
+    net.init(None)                                   # was: net.init(sess) after tf.Session()
+    outs = net.inference(image_v, hand_side_v, True) # was: sess.run([...6 tensors...], feed_dict)
+"""
+from __future__ import print_function, unicode_literals
+
+import os
+import pickle
+
+import numpy as np
+
+from .._lib import Engine
+
+
+def load_weight_files(engine, weight_files, exclude_var_list=None, verbose=True):
+    """The loading loop of ColorHandPose3DNetwork.init (:50-59) / PosePriorNetwork.init (:47-57):
+    unpickle dict[str -> ndarray], drop keys containing any exclude substring, assign by name."""
+    if exclude_var_list is None:
+        exclude_var_list = list()
+    for file_name in weight_files:
+        assert os.path.exists(file_name), "File not found."
+        with open(file_name, 'rb') as fi:
+            weight_dict = pickle.load(fi, encoding='latin1')
+            weight_dict = {k: v for k, v in weight_dict.items() if not any([x in k for x in exclude_var_list])}
+            if len(weight_dict) > 0:
+                engine.load_weight_dict(weight_dict)
+                if verbose:
+                    print('Loaded %d variables from %s' % (len(weight_dict), file_name))
+    engine.finalize_weights()
+
+
+class ColorHandPose3DNetwork(object):
+    """ Network performing 3D pose estimation of a human hand from a single color image. """
+
+    def __init__(self, device=0, engine=None):
+        self.crop_size = 256
+        self.num_kp = 21
+        self.engine = engine if engine is not None else Engine(device)
+
+    def init(self, session=None, weight_files=None, exclude_var_list=None):
+        """ Initializes weights from pickled python dictionaries (reference :34-59).
+            `session` is accepted for call compatibility and ignored. """
+        if weight_files is None:
+            weight_files = ['./weights/handsegnet-rhd.pickle', './weights/posenet3d-rhd-stb-slr-finetuned.pickle']
+        load_weight_files(self.engine, weight_files, exclude_var_list)
+
+    def init_from_dict(self, weight_dict):
+        """Convenience for synthetic weights: the merged content of the weight files."""
+        self.engine.load_weight_dict(weight_dict)
+        self.engine.finalize_weights()
+
+    @staticmethod
+    def _check_eval(evaluation):
+        if not bool(evaluation):
+            raise NotImplementedError("inference engine: evaluation=False (dropout active) is a training path")
+
+    def inference(self, image, hand_side, evaluation):
+        """ Full pipeline: HandSegNet + PoseNet + PosePrior (reference :61-99).
+            Returns hand_scoremap [B,H,W,2], image_crop [B,256,256,3], scale_crop [B,1],
+            center [B,2] (row, col), keypoints_scoremap [B,256,256,21], keypoint_coord3d [B,21,3]. """
+        self._check_eval(evaluation)
+        o = self.engine.infer_full(image, hand_side)
+        return o['scoremap'], o['crop'], o['scale'], o['center'], o['kpmap'], o['coord3d']
+
+    def inference2d(self, image):
+        """ Only 2D part of the pipeline: HandSegNet + PoseNet (reference :101-129).
+            Returns keypoints_scoremap, image_crop, scale_crop, center -- note the order. """
+        return self.engine.infer_2d(image)
+
+    def inference_detection(self, image, train=False):
+        """ HandSegNet (reference :131-168).  Returns a list (len 1) of [B,H,W,2] score maps. """
+        if train:
+            raise NotImplementedError("inference engine: train=True is not supported")
+        return [self.engine.handsegnet(image)]
+
+    def inference_pose2d(self, image_crop, train=False):
+        """ PoseNet (reference :170-219).  Returns the list of 3 [B,h/8,w/8,21] score maps. """
+        if train:
+            raise NotImplementedError("inference engine: train=True is not supported")
+        return self.engine.posenet2d(image_crop)
+
+    def _inference_pose3d(self, keypoints_scoremap, hand_side, evaluation, train=False):
+        """ PosePrior + Viewpoint on a [B,32,32,21] score map (reference :221-247). """
+        self._check_eval(evaluation)
+        return self.engine.pose3d(keypoints_scoremap, hand_side)[0]

@@ -1,0 +1,37 @@
+"""PosePriorNetwork -- nets/PosePriorNetwork.py:30-95 of the reference on the MI355X engine.
+
+Variants 'direct', 'bottleneck', 'proposed' run on the engine; 'local' / 'local_w_xyz_loss' need
+bone_rel_trafo_inv (utils/relative_trafo.py) and raise NotImplementedError.
+"""
+from __future__ import print_function, unicode_literals
+
+from .._lib import Engine
+from .ColorHandPose3DNetwork import load_weight_files
+
+
+class PosePriorNetwork(object):
+    """ Network containing different variants for lifting 2D predictions into 3D. """
+
+    def __init__(self, variant, device=0, engine=None):
+        self.num_kp = 21
+        self.variant = variant
+        self.engine = engine if engine is not None else Engine(device)
+
+    def init(self, session=None, weight_files=None, exclude_var_list=None):
+        """ reference :36-57 -- weight_files is required there (no default). """
+        assert weight_files is not None, "weight_files is required"
+        load_weight_files(self.engine, weight_files, exclude_var_list)
+
+    def init_from_dict(self, weight_dict):
+        self.engine.load_weight_dict(weight_dict)
+        self.engine.finalize_weights()
+
+    def inference(self, scoremap, hand_side, evaluation):
+        """ Infere 3D coordinates from 2D scoremaps (reference :59-95).
+            Returns (coord_xyz_rel_normed, coord3d, R); R is None for direct/bottleneck. """
+        if not bool(evaluation):
+            raise NotImplementedError("inference engine: evaluation=False (dropout active) is a training path")
+        if self.variant in ('local', 'local_w_xyz_loss'):
+            raise NotImplementedError("variant %r needs bone_rel_trafo_inv (SURVEY.md 8f N3)" % self.variant)
+        assert self.variant in ('direct', 'bottleneck', 'proposed'), "Unknown variant."
+        return self.engine.poseprior(self.variant, scoremap, hand_side)

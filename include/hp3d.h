@@ -140,8 +140,8 @@ int hp3d_fc(hp3d_ctx* ctx, const float* x, int B, int Cin, const float* w, const
 int hp3d_argmax2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int32_t* out_rc);
 
 /* ---- measurement ------------------------------------------------------------------------
- * With profiling on, every launch of the last whole-path call is bracketed by hipEvents on
- * the ctx stream.  hp3d_prof_get(i): layer name, kernel family, ms, algorithmic FLOPs and
+ * With profiling on (1: last whole-path call only, 2: accumulate over calls until switched off),
+ * every launch is bracketed by hipEvents on the ctx stream.  hp3d_prof_get(i): layer name, kernel family, ms, algorithmic FLOPs and
  * algorithmic bytes (input once + weights once + output once).                */
 int hp3d_set_profiling(hp3d_ctx* ctx, int on);
 int hp3d_prof_count(hp3d_ctx* ctx);

@@ -1,0 +1,106 @@
+"""The product kernel sources + executor, interpreted on the CPU (tests/emu), vs the oracle on
+small shapes: tile maps, halo zero-fill, weight packing, concat-channel permutation, masked edge
+tiles, stride-2 SAME asymmetry, fused pool, mask growth, lifting head.  Runs without a GPU."""
+import os
+
+import numpy as np
+import pytest
+
+from hand3d_amd import synth
+from oracle import general as G
+from oracle import nets as N
+from oracle import tf_ops as T
+
+CASES = [(1, 16, 16, 32, 32, 3, 1, 0), (2, 10, 20, 40, 70, 3, 1, 0), (1, 16, 32, 64, 128, 3, 1, 1),
+         (1, 12, 12, 21, 32, 3, 2, 0), (1, 9, 9, 33, 64, 3, 2, 0), (1, 8, 8, 32, 21, 1, 1, 0),
+         (1, 9, 11, 35, 32, 7, 1, 0), (1, 6, 10, 64, 160, 1, 1, 0), (1, 10, 18, 32, 64, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "B%d_%dx%d_%d-%d_k%ds%dp%d" % c)
+def test_conv_kernel_on_interpreter(emu_engine, case):
+    B, H, W, Cin, Cout, k, s, pool = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, s, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    assert np.abs(emu_engine.conv2d(x, w, b, s, True, bool(pool)) - r).max() < 1e-5
+
+
+def test_glue_kernels_on_interpreter(emu_engine):
+    e = emu_engine
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 6, 8, 5)).astype(np.float32)
+    assert np.array_equal(e.maxpool2(x), T.max_pool_2x2(x))
+    x = rng.standard_normal((1, 16, 24, 3)).astype(np.float32)
+    assert np.abs(e.avgpool8(x) - T.avg_pool_8x8(x)).max() < 1e-6
+    x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
+    assert np.array_equal(e.resize_bilinear(x, 40, 56), T.resize_bilinear_legacy(x, 40, 56))
+    img = rng.uniform(-.5, .5, (3, 40, 56, 3)).astype(np.float32)
+    c = np.array([[20, 30], [5, 50], [39.5, 2]], np.float32)
+    s = np.array([5.0, 1.3, 0.25], np.float32)
+    assert np.array_equal(e.crop_and_resize(img, c, s, 64), G.crop_image_from_xy(img, c, 64, s))
+    x = rng.standard_normal((5, 300)).astype(np.float32)
+    w = (rng.standard_normal((300, 70)) / 17).astype(np.float32)
+    b = rng.standard_normal(70).astype(np.float32)
+    assert np.abs(e.fc(x, w, b, True) - T.leaky_relu(T.fully_connected(x, w, b, np.float64))).max() < 1e-5
+    x = rng.standard_normal((2, 16, 16, 21)).astype(np.float32)
+    x[0, 3, 4, 2] = x[0, 9, 9, 2] = 50
+    ref = np.array([[np.unravel_index(np.argmax(x[b, :, :, c]), (16, 16)) for c in range(21)] for b in range(2)])
+    assert np.array_equal(e.argmax2d(x), ref)
+
+
+def test_mask_growth_on_interpreter(emu_engine):
+    rng = np.random.default_rng(2)
+    small = rng.standard_normal((2, 8, 12, 2)).astype(np.float32)
+    sm = T.resize_bilinear_legacy(small, 64, 96)
+    mask, center, size, scale, seed = emu_engine.mask_from_scoremap(sm)
+    rm = G.single_obj_scoremap(sm)[..., 0]
+    rc, _, rs = G.calc_center_bb(rm[..., None])
+    assert np.array_equal(mask, rm) and np.array_equal(center, rc) and np.array_equal(size, rs)
+    assert np.array_equal(seed, G.find_max_location(G.fg_and_detmap(sm)[0]))
+    assert np.array_equal(scale, G.scale_from_crop_size(rs))
+    # empty mask fallbacks (utils/general.py:311-320) and the 32-pass cap on a 1-px-wide spiral
+    empty = np.zeros((1, 40, 64, 2), np.float32)
+    empty[..., 1] = -2
+    _, c, s_, _, _ = emu_engine.mask_from_scoremap(empty)
+    assert c.tolist() == [[160.0, 160.0]] and s_.tolist() == [[100.0]]
+    with pytest.raises(AssertionError):
+        emu_engine.mask_from_scoremap(np.zeros((5, 4, 9, 2), np.float32))   # reference asserts B < H, W
+
+
+def test_networks_on_interpreter(emu_engine, synth_weights):
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights)
+    img = synth.make_batch(3, 1, 16, 24)
+    large, small = emu_engine.handsegnet(img, want_small=True)
+    rs, rl = N.handsegnet(synth_weights, img, acc=np.float64)
+    assert np.abs(small - rs).max() < 1e-5 and np.abs(large - rl[0]).max() < 1e-5
+    crop = synth.make_batch(9, 1, 16, 16)
+    sms = net.inference_pose2d(crop)           # exercises the concat-channel permutation of conv6_1/conv7_1
+    ref = N.posenet2d(synth_weights, crop, acc=np.float64)
+    for a, b in zip(sms, ref):
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-5
+    rng = np.random.default_rng(5)
+    sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
+    hs = synth.hand_sides(2)
+    rel, can, R = emu_engine.pose3d(sm32, hs)
+    rrel, rcan, rR = N.pose3d(synth_weights, sm32, hs, acc=np.float64)
+    assert np.abs(rel - rrel).max() < 1e-5 and np.abs(can - rcan).max() < 1e-5 and np.abs(R - rR).max() < 1e-5
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(os.environ.get('HP3D_SLOW') != '1', reason="~3 min on the CPU interpreter; set HP3D_SLOW=1")
+def test_full_pipeline_on_interpreter(emu_engine, synth_weights):
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights)
+    img = synth.make_batch(1, 1, 48, 64)
+    hs = synth.hand_sides(1)
+    out = net.inference(img, hs, True)
+    ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
+    for a, b in zip(out, ref):
+        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4

@@ -1,0 +1,348 @@
+"""GPU parity tests proper: libhp3d.so (hand-written HIP, gfx950) vs the oracle, through the C ABI.
+
+Tolerances (BASELINE.json north_star): heat-maps 1e-3, 3-D keypoints 1e-4, max-abs, against the
+float64-accumulating oracle; integer/index outputs (masks, seeds, arg-max) bit-exact.
+PARITY UNPINNED against TF 1.3 itself (see oracle/__init__.py).
+"""
+import numpy as np
+import pytest
+
+from hand3d_amd import synth
+from oracle import general as G
+from oracle import nets as N
+from oracle import tf_ops as T
+
+pytestmark = pytest.mark.gpu
+
+TOL_HEATMAP = 1e-3
+TOL_KP3D = 1e-4
+
+
+def _conv_ref(x, w, b, stride, act, pool):
+    r = T.bias_add(T.conv2d_same(x, w, stride, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    if pool:
+        r = T.max_pool_2x2(r)
+    return r
+
+
+# (B,H,W,Cin,Cout,k,stride,pool): the layer geometries of SURVEY.md App. A + ragged/edge cases
+CONV_CASES = [
+    (1, 240, 320, 64, 64, 3, 1, 1),     # HandSegNet conv1_2 + pool1
+    (2, 120, 160, 64, 128, 3, 1, 0),    # conv2_1
+    (1, 60, 80, 256, 256, 3, 1, 1),     # conv3_4 + pool3 (60 rows: masked 8-row tiles)
+    (2, 30, 40, 512, 512, 3, 1, 0),     # conv4_x (30x40: 8x8 tiles with masking)
+    (1, 30, 40, 512, 128, 3, 1, 0),     # conv5_2
+    (1, 30, 40, 128, 512, 1, 1, 0),     # conv6_1 (1x1)
+    (1, 30, 40, 512, 2, 1, 1, 0),       # conv6_2 head (Cout=2)
+    (1, 32, 32, 149, 128, 7, 1, 0),     # PoseNet conv6_1 (7x7, Cin=149)
+    (2, 32, 32, 128, 128, 7, 1, 0),     # conv6_2..5
+    (1, 32, 32, 128, 21, 1, 1, 0),      # conv6_7 head (Cout=21)
+    (3, 32, 32, 21, 32, 3, 1, 0),       # conv_pose_0_1
+    (3, 32, 32, 32, 32, 3, 2, 0),       # conv_pose_0_2 stride 2 (asymmetric SAME pad)
+    (2, 8, 8, 128, 128, 3, 2, 0),       # conv_pose_2_2 -> 4x4
+    (2, 8, 8, 256, 256, 3, 2, 0),       # conv_vp_2_2
+    (1, 17, 23, 37, 45, 3, 1, 0),       # ragged everything
+    (1, 18, 22, 40, 64, 3, 1, 1),       # ragged + pool
+    (1, 15, 15, 32, 32, 3, 2, 0),       # odd size stride 2 (symmetric pad case)
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_k%ds%dp%d" % c)
+def test_conv_mfma_vs_oracle(gpu_engine, case):
+    B, H, W, Cin, Cout, k, stride, pool = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    act = Cout not in (2, 21)
+    y = gpu_engine.conv2d(x, w, b, stride, act, pool)
+    r = _conv_ref(x, w, b, stride, act, pool)
+    assert y.shape == r.shape
+    err = np.abs(y - r).max()
+    print("conv %s max|err| %.3e" % (case, err))
+    assert err < 5e-5, err   # f32 accumulation over K <= 7301 vs the f64 oracle, unit-variance data
+
+
+def test_conv_mfma_vs_naive_kernel(gpu_engine):
+    """Same op through the obviously-correct one-thread-per-output kernel (debug path)."""
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((1, 24, 40, 96)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 96, 160)) / 30).astype(np.float32)
+    b = rng.standard_normal(160).astype(np.float32)
+    y = gpu_engine.conv2d(x, w, b, 1, True, False)
+    gpu_engine.set_option('conv_impl', 'naive')
+    try:
+        y2 = gpu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+    assert np.abs(y - y2).max() < 2e-5
+
+
+def test_conv_linearity_full_size(gpu_engine):
+    """Size-independent property at a BASELINE-size layer (B=8, 80x80, 256->256): without bias
+    and activation conv(a*x1 + x2) == a*conv(x1) + conv(x2) to rounding."""
+    rng = np.random.default_rng(11)
+    x1 = rng.standard_normal((8, 80, 80, 256)).astype(np.float32)
+    x2 = rng.standard_normal((8, 80, 80, 256)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 256, 256)) / 48).astype(np.float32)
+    b = np.zeros(256, np.float32)
+    y1 = gpu_engine.conv2d(x1, w, b, 1, False, False)
+    y2 = gpu_engine.conv2d(x2, w, b, 1, False, False)
+    y3 = gpu_engine.conv2d(2.0 * x1 + x2, w, b, 1, False, False)
+    assert np.abs(y3 - (2.0 * y1 + y2)).max() < 5e-5
+
+
+def test_glue_ops_bit_exact(gpu_engine):
+    e = gpu_engine
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((2, 60, 80, 37)).astype(np.float32)
+    assert np.array_equal(e.maxpool2(x), T.max_pool_2x2(x))
+    x = rng.standard_normal((2, 256, 256, 21)).astype(np.float32)
+    assert np.abs(e.avgpool8(x) - T.avg_pool_8x8(x)).max() < 1e-6
+    x = rng.standard_normal((2, 30, 40, 2)).astype(np.float32)
+    assert np.array_equal(e.resize_bilinear(x, 240, 320), T.resize_bilinear_legacy(x, 240, 320))
+    x = rng.standard_normal((1, 32, 32, 21)).astype(np.float32)
+    assert np.array_equal(e.resize_bilinear(x, 256, 256), T.resize_bilinear_legacy(x, 256, 256))
+    assert np.array_equal(e.resize_bilinear(x, 32, 32), x)   # equal sizes => identity
+
+
+def test_crop_and_resize_vs_oracle(gpu_engine):
+    rng = np.random.default_rng(2)
+    img = rng.uniform(-.5, .5, (6, 240, 320, 3)).astype(np.float32)
+    center = np.array([[120, 160], [5, 300], [239.5, 2], [160, 160], [0, 0], [53, 41]], np.float32)
+    scale = np.array([1.0, 5.0, 0.25, 3.1030303, 0.5, 2.2], np.float32)   # incl. both clip ends
+    y = gpu_engine.crop_and_resize(img, center, scale, 256)
+    r = G.crop_image_from_xy(img, center, 256, scale)
+    assert np.array_equal(y == 0, r == 0), "extrapolated (zero) region differs"
+    assert np.abs(y - r).max() < 1e-6
+
+
+def test_fc_vs_oracle(gpu_engine):
+    rng = np.random.default_rng(3)
+    for B, Cin, Cout, act in [(1, 2050, 512, True), (32, 4098, 256, True), (5, 512, 63, False), (3, 128, 3, False)]:
+        x = rng.standard_normal((B, Cin)).astype(np.float32)
+        w = (rng.standard_normal((Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+        b = rng.standard_normal(Cout).astype(np.float32)
+        r = T.fully_connected(x, w, b, np.float64)
+        if act:
+            r = T.leaky_relu(r)
+        assert np.abs(gpu_engine.fc(x, w, b, act) - r).max() < 1e-5
+
+
+def test_argmax2d_first_index(gpu_engine):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 256, 256, 21)).astype(np.float32)
+    x[0, 10, 20, 3] = x[0, 200, 5, 3] = 99.0        # tie: first (row-major) wins
+    x[1, :, :, 7] = -1.5                            # all equal -> index 0
+    got = gpu_engine.argmax2d(x)
+    for b in range(2):
+        for c in range(21):
+            v, u = np.unravel_index(np.argmax(x[b, :, :, c]), (256, 256))
+            assert tuple(got[b, c]) == (v, u)
+
+
+def _blob_scoremap(H, W, boxes, seedpix=None, base=-3.0):
+    sm = np.zeros((1, H, W, 2), np.float32)
+    sm[..., 1] = base
+    for (y0, y1, x0, x1, v) in boxes:
+        sm[0, y0:y1, x0:x1, 1] = v
+    if seedpix:
+        sm[0, seedpix[0], seedpix[1], 1] = 9.0
+    return sm
+
+
+def test_mask_engineered_cases(gpu_engine):
+    H, W = 240, 320
+    cases = {
+        'two_blobs_far': _blob_scoremap(H, W, [(20, 60, 30, 90, 2.0), (150, 220, 200, 300, 2.5)]),
+        'two_blobs_gap10': _blob_scoremap(H, W, [(50, 80, 50, 100, 2.0), (50, 80, 110, 160, 3.0)]),   # gap 10 px: bridged
+        'two_blobs_gap11': _blob_scoremap(H, W, [(50, 80, 50, 100, 2.0), (50, 80, 111, 160, 3.0)]),   # gap 11 px: not bridged
+        'empty': _blob_scoremap(H, W, []),
+        'full': _blob_scoremap(H, W, [(0, H, 0, W, 1.0)]),
+        'single_pixel': _blob_scoremap(H, W, [(77, 78, 123, 124, 4.0)]),
+        'border': _blob_scoremap(H, W, [(0, 5, 0, W, 2.0), (0, H, W - 3, W, 2.0)], seedpix=(0, 0)),
+    }
+    # a serpentine needing more than 32 passes: the pass cap must bite identically
+    sm = _blob_scoremap(H, W, [])
+    for i, y in enumerate(range(4, 236, 24)):
+        sm[0, y:y + 2, 4:316, 1] = 2.0
+        xs = 314 if i % 2 == 0 else 4
+        sm[0, y:y + 26, xs:xs + 2, 1] = 2.0
+    sm[0, 4, 4, 1] = 9.0
+    cases['serpentine_pass_cap'] = sm
+    for name, sm in cases.items():
+        mask, center, size, scale, seed = gpu_engine.mask_from_scoremap(sm)
+        rm = G.single_obj_scoremap(sm)[..., 0]
+        rc, _, rs = G.calc_center_bb(rm[..., None])
+        fg, _ = G.fg_and_detmap(sm)
+        assert np.array_equal(seed, G.find_max_location(fg)), name
+        assert np.array_equal(mask, rm), (name, mask.sum(), rm.sum())
+        assert np.array_equal(center, rc) and np.array_equal(size, rs), (name, center, rc, size, rs)
+        assert np.array_equal(scale, G.scale_from_crop_size(rs)), name
+    rm = G.single_obj_scoremap(cases['serpentine_pass_cap'])[..., 0]
+    full = G.grow_objectmap(G.fg_and_detmap(cases['serpentine_pass_cap'])[1][0], (4, 4), num_passes=500, early_exit=True)[0]
+    assert rm.sum() < full.sum(), "test input does not exercise the 32-pass cap"
+
+
+def test_mask_empty_reduce_option(gpu_engine):
+    sm = _blob_scoremap(240, 320, [])
+    gpu_engine.set_option('empty_reduce', 'fltmax')
+    try:
+        _, center, size, _, _ = gpu_engine.mask_from_scoremap(sm)
+    finally:
+        gpu_engine.set_option('empty_reduce', 'inf')
+    assert center.tolist() == [[0.0, 0.0]] and size.tolist() == [[100.0]]
+    _, center, size, _, _ = gpu_engine.mask_from_scoremap(sm)
+    assert center.tolist() == [[160.0, 160.0]] and size.tolist() == [[100.0]]
+
+
+@pytest.fixture(scope='module')
+def net(gpu_engine, synth_weights):
+    from hand3d_amd import ColorHandPose3DNetwork
+    n = ColorHandPose3DNetwork(engine=gpu_engine)
+    n.init_from_dict(synth_weights)
+    return n
+
+
+def test_handsegnet_parity(net, synth_weights):
+    img = synth.make_batch(0, 2, 240, 320)
+    large, small = net.engine.handsegnet(img, want_small=True)
+    rs, rl = N.handsegnet(synth_weights, img, acc=np.float64)
+    print("HandSegNet small err %.3e large err %.3e" % (np.abs(small - rs).max(), np.abs(large - rl[0]).max()))
+    assert np.abs(small - rs).max() < TOL_HEATMAP / 10
+    assert np.abs(large - rl[0]).max() < TOL_HEATMAP / 10
+    assert np.array_equal(net.inference_detection(img)[0], large)
+
+
+def test_posenet_parity_config_c2(net, synth_weights):
+    """BASELINE config 2: PoseNet-only, 256x256 crop, batch 1 (seed 100)."""
+    crop = synth.make_batch(100, 1, 256, 256)
+    sms = net.inference_pose2d(crop)
+    ref = N.posenet2d(synth_weights, crop, acc=np.float64)
+    assert len(sms) == 3
+    for a, b in zip(sms, ref):
+        assert a.shape == (1, 32, 32, 21)
+        print("PoseNet2D scoremap err %.3e (|ref| max %.3f)" % (np.abs(a - b).max(), np.abs(b).max()))
+        assert np.abs(a - b).max() < TOL_HEATMAP / 10
+
+
+def test_pose3d_and_poseprior_variants(gpu_engine, synth_weights):
+    from hand3d_amd import PosePriorNetwork
+    rng = np.random.default_rng(8)
+    B = 5
+    sm256 = np.maximum(rng.standard_normal((B, 256, 256, 21)).astype(np.float32), 0) * 0.2
+    hs = synth.hand_sides(B)
+    wprior = {k: v for k, v in synth_weights.items() if k.startswith(('PosePrior', 'ViewpointNet'))}
+    p = PosePriorNetwork('proposed', engine=gpu_engine)
+    p.init_from_dict(wprior)
+    rel, c3d, R = p.inference(sm256, hs, True)
+    rrel, rc3d, rR = N.poseprior_network(synth_weights, 'proposed', sm256, hs, acc=np.float64)
+    assert np.abs(rel - rrel).max() < TOL_KP3D and np.abs(c3d - rc3d).max() < TOL_KP3D and np.abs(R - rR).max() < TOL_KP3D
+    assert np.abs(np.einsum('bij,bkj->bik', R, R) - np.eye(3)).max() < 1e-5   # rotation matrices
+    d = PosePriorNetwork('direct', engine=gpu_engine)
+    rel, c3d, R = d.inference(sm256, hs, True)
+    rrel, _, _ = N.poseprior_network(synth_weights, 'direct', sm256, hs, acc=np.float64)
+    assert R is None and np.abs(rel - rrel).max() < TOL_KP3D and np.array_equal(rel, c3d)
+    wb = synth.make_weights(bottleneck=True)
+    wbp = {k: v for k, v in wb.items() if k.startswith('PosePrior')}
+    bn = PosePriorNetwork('bottleneck', engine=gpu_engine)
+    bn.init_from_dict(wbp)
+    rel, _, R = bn.inference(sm256, hs, True)
+    rrel, _, _ = N.poseprior_network(wb, 'bottleneck', sm256, hs, acc=np.float64)
+    assert R is None and np.abs(rel - rrel).max() < TOL_KP3D
+    with pytest.raises(NotImplementedError):
+        PosePriorNetwork('local', engine=gpu_engine).inference(sm256, hs, True)
+    # restore the standard weight set for later tests
+    gpu_engine.load_weight_dict(synth_weights)
+    gpu_engine.finalize_weights()
+
+
+def _full_parity(net, weights, img, hs):
+    o = net.engine.infer_full(img, hs, want_mask=True)
+    taps = {}
+    ref = N.inference(weights, img, hs, True, acc=np.float64, taps=taps)
+    rmask = taps['hand_mask'][..., 0]
+    rep = dict(
+        scoremap=np.abs(o['scoremap'] - ref[0]).max(),
+        mask_equal=bool(np.array_equal(o['mask'], rmask)),
+        mask_diff_px=int((o['mask'] != rmask).sum()),
+        center=np.abs(o['center'] - ref[3]).max(), scale=np.abs(o['scale'] - ref[2]).max(),
+        crop=np.abs(o['crop'] - ref[1]).max(), kpmap=np.abs(o['kpmap'] - ref[4]).max(),
+        coord3d=np.abs(o['coord3d'] - ref[5]).max())
+    return o, ref, rep
+
+
+def test_full_pipeline_parity_config_c1(net, synth_weights):
+    """BASELINE config 1 shape: inference(), B=1, 240x320, 5 seeded images, hand_side [[1,0]]."""
+    from hand3d_amd.utils.general import EvalUtil
+    ev = EvalUtil()
+    for seed in range(5):
+        img = synth.make_batch(seed, 1, 240, 320)
+        hs = np.array([[1.0, 0.0]], np.float32)
+        o, ref, rep = _full_parity(net, synth_weights, img, hs)
+        print("seed %d: %s" % (seed, rep))
+        assert rep['scoremap'] < TOL_HEATMAP
+        assert rep['mask_equal'], "mask differs in %d px (knife-edge?)" % rep['mask_diff_px']
+        assert rep['center'] == 0 and rep['scale'] == 0
+        assert rep['crop'] < 1e-5
+        assert rep['kpmap'] < TOL_HEATMAP
+        assert rep['coord3d'] < TOL_KP3D
+        ev.feed(ref[5][0], np.ones(21), o['coord3d'][0])
+    mean_epe, _, _, _, _ = ev.get_measures(0.0, 0.05, 20)
+    print("mean EPE engine vs oracle: %.3e" % mean_epe)
+    assert mean_epe < TOL_KP3D
+
+
+def test_full_pipeline_batch_and_2d(net, synth_weights):
+    """B=4 with alternating hand sides == four B=1 calls; inference2d return order."""
+    img = synth.make_batch(300, 4, 240, 320)
+    hs = synth.hand_sides(4)
+    o = net.inference(img, hs, True)
+    assert [a.shape for a in o] == [(4, 240, 320, 2), (4, 256, 256, 3), (4, 1), (4, 2), (4, 256, 256, 21), (4, 21, 3)]
+    for i in range(4):
+        oi = net.inference(img[i:i + 1], hs[i:i + 1], True)
+        for a, b in zip(o, oi):
+            assert np.array_equal(a[i:i + 1], b), "batched result differs from single-image result"
+    kp, crop, scale, center = net.inference2d(img)
+    assert np.array_equal(kp, o[4]) and np.array_equal(crop, o[1]) and np.array_equal(scale, o[2]) and np.array_equal(center, o[3])
+    ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
+    assert np.abs(o[5] - ref[5]).max() < TOL_KP3D and np.abs(o[4] - ref[4]).max() < TOL_HEATMAP
+
+
+def test_full_pipeline_320x320_and_determinism(net, synth_weights):
+    """BASELINE config 3 shape (raw 320x320 RHD frame) + run-to-run bit reproducibility."""
+    img = synth.make_batch(200, 2, 320, 320)
+    hs = synth.hand_sides(2)
+    o1 = net.inference(img, hs, True)
+    o2 = net.inference(img, hs, True)
+    for a, b in zip(o1, o2):
+        assert np.array_equal(a, b)
+    ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
+    assert np.abs(o1[0] - ref[0]).max() < TOL_HEATMAP
+    assert np.array_equal(o1[3], ref[3]) and np.array_equal(o1[2], ref[2])
+    assert np.abs(o1[4] - ref[4]).max() < TOL_HEATMAP and np.abs(o1[5] - ref[5]).max() < TOL_KP3D
+
+
+def test_golden_fixtures_gpu(net, synth_weights):
+    """The committed golden vectors (tests/golden, made by scripts/make_golden.py from the oracle)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'e2e_240x320_seed0.npz'))
+    img = synth.make_batch(0, 1, 240, 320)
+    o = net.inference(img, np.array([[1.0, 0.0]], np.float32), True)
+    assert np.array_equal(o[3], g['center']) and np.array_equal(o[2], g['scale_crop'])
+    assert np.abs(o[5] - g['keypoint_coord3d']).max() < TOL_KP3D
+    assert np.abs(o[4][0, ::8, ::8, :] - g['scoremap32']).max() < TOL_HEATMAP
+
+
+def test_errors_are_loud(gpu_engine):
+    from hand3d_amd import ColorHandPose3DNetwork, Engine
+    with pytest.raises(AssertionError):
+        ColorHandPose3DNetwork(engine=gpu_engine).init(None, weight_files=['/nonexistent.pickle'])
+    e2 = Engine(0)
+    with pytest.raises(Exception):
+        e2.infer_full(np.zeros((1, 240, 320, 3), np.float32), np.zeros((1, 2), np.float32))   # no weights
+    with pytest.raises(AssertionError):
+        gpu_engine.handsegnet(np.zeros((1, 100, 100, 3), np.float32))   # H,W not multiples of 8
+    e2.close()

@@ -1,0 +1,86 @@
+"""The Python call surface mirrors the reference's (names, argument order, return order, errors):
+nets/ColorHandPose3DNetwork.py:28-219, nets/PosePriorNetwork.py:30-95, weight loading :34-59."""
+import inspect
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+from hand3d_amd import ColorHandPose3DNetwork, PosePriorNetwork, arch, synth
+
+
+def test_method_surface_matches_reference():
+    sig = lambda f: list(inspect.signature(f).parameters)
+    assert sig(ColorHandPose3DNetwork.init) == ['self', 'session', 'weight_files', 'exclude_var_list']
+    assert sig(ColorHandPose3DNetwork.inference) == ['self', 'image', 'hand_side', 'evaluation']
+    assert sig(ColorHandPose3DNetwork.inference2d) == ['self', 'image']
+    assert sig(ColorHandPose3DNetwork.inference_detection) == ['self', 'image', 'train']
+    assert sig(ColorHandPose3DNetwork.inference_pose2d) == ['self', 'image_crop', 'train']
+    assert sig(PosePriorNetwork.__init__)[:2] == ['self', 'variant']
+    assert sig(PosePriorNetwork.init) == ['self', 'session', 'weight_files', 'exclude_var_list']
+    assert sig(PosePriorNetwork.inference) == ['self', 'scoremap', 'hand_side', 'evaluation']
+
+
+def test_arch_tables_match_survey():
+    shapes = arch.var_shapes(arch.all_layers())
+    assert sum(int(np.prod(s)) for s in shapes.values()) == 34996515          # SURVEY.md App. A grand total
+    assert shapes['PoseNet2D/conv6_1/weights'] == (7, 7, 149, 128)
+    assert shapes['PosePrior/fc_rel0/weights'] == (2050, 512) and shapes['ViewpointNet/fc_vp0/weights'] == (4098, 256)
+    assert shapes['HandSegNet/conv6_2/weights'] == (1, 1, 512, 2)
+    f = arch.pipeline_flops(240, 320)
+    assert abs(f['total'] / 1e9 - 121.83) < 0.01 and abs(arch.pipeline_flops(320, 320)['total'] / 1e9 - 142.26) < 0.01
+
+
+def test_weight_files_loading_and_exclusion(tmp_path, emu_engine, synth_weights):
+    paths = synth.write_weight_files(str(tmp_path), synth_weights)
+    with open(paths[1], 'rb') as f:
+        d = pickle.load(f)
+    assert 'PoseNet2D/conv1_1/weights' in d and d['PosePrior/fc_xyz/weights'].dtype == np.float32
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    assert net.crop_size == 256 and net.num_kp == 21
+    net.init(None, weight_files=paths)
+    assert emu_engine.nets_mask() & 15 == 15
+    # eval2d.py:78-79: posenet weights without the lifting nets
+    from hand3d_amd import Engine
+    e2 = Engine(0, path=os.environ.get('HP3D_LIB') or emu_engine.lib._name)
+    net2 = ColorHandPose3DNetwork(engine=e2)
+    net2.init(None, weight_files=paths, exclude_var_list=['PosePrior', 'ViewpointNet'])
+    assert e2.nets_mask() & 15 == 3
+    with pytest.raises(Exception):
+        net2.inference(np.zeros((1, 16, 24, 3), np.float32), np.array([[1., 0.]], np.float32), True)  # lifting nets absent
+    with pytest.raises(AssertionError, match="File not found."):
+        net2.init(None, weight_files=[str(tmp_path / 'missing.pickle')])
+    e2.close()
+
+
+def test_error_behaviour(emu_engine, synth_weights):
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights)
+    img = np.zeros((1, 16, 24, 3), np.float32)
+    with pytest.raises(NotImplementedError):
+        net.inference(img, np.array([[1., 0.]], np.float32), False)      # dropout path = training
+    with pytest.raises(NotImplementedError):
+        net.inference_pose2d(img, train=True)
+    with pytest.raises(AssertionError):
+        net.inference_detection(np.zeros((1, 20, 24, 3), np.float32))     # H not a multiple of 8
+    with pytest.raises(AssertionError):
+        emu_engine.set_weight('HandSegNet/conv1_1/weights', np.zeros((3, 3, 3, 63), np.float32))   # bad shape
+    with pytest.raises(AssertionError):
+        emu_engine.set_weight('HandSegNet/nope/weights', np.zeros((1,), np.float32))
+    with pytest.raises(AssertionError, match="Unknown variant."):
+        PosePriorNetwork('bogus', engine=emu_engine).inference(np.zeros((1, 256, 256, 21), np.float32),
+                                                                np.array([[1., 0.]], np.float32), True)
+    with pytest.raises(NotImplementedError):
+        PosePriorNetwork('local', engine=emu_engine).inference(np.zeros((1, 256, 256, 21), np.float32),
+                                                               np.array([[1., 0.]], np.float32), True)
+
+
+def test_incomplete_network_is_rejected(emu_engine, synth_weights):
+    from hand3d_amd import Engine, Hp3dError
+    e2 = Engine(0, path=emu_engine.lib._name)
+    part = {k: v for k, v in synth_weights.items() if k.startswith('HandSegNet/conv1')}
+    e2.load_weight_dict(part)
+    with pytest.raises(Hp3dError):
+        e2.finalize_weights()
+    e2.close()

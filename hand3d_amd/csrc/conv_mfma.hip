@@ -22,6 +22,7 @@
 //     barrier per tap; two workgroups per CU hide the remaining staging latency.
 #include "hp3d_common.h"
 #include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -37,7 +38,7 @@ struct ConvCfg {
     static constexpr int PW = (TW - 1) * STRIDE + KS;
     static constexpr int PATCH_FLOATS = ((PH * PW * LDA + 3) / 4) * 4;
     static constexpr int WBUF_FLOATS = CK * BN;
-    static constexpr int SMEM_BYTES = (PATCH_FLOATS + 2 * WBUF_FLOATS) * 4;
+    static constexpr int SMEM_BYTES = (PATCH_FLOATS + 3 * WBUF_FLOATS) * 4;
     static constexpr int WVEC = (CK * BN / 4) / NTHR;   // float4 of weights per thread per tap
     static_assert(BM == WM * MT * 32, "tile/wave mismatch");
     static_assert(TH == WM * MT * (32 / TW), "tile rows mismatch");
@@ -93,65 +94,124 @@ void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    f32x4 wreg[C::WVEC];
-    auto w_fetch = [&](int tap, int chunk) {
+    // patch staging, split into issue (global -> registers) and commit (registers -> LDS) so the
+    // next chunk's patch is in flight while the current chunk's last tap computes
+    constexpr int PVEC = (PH * PW * 8 + NTHR - 1) / NTHR;
+    int poff[PVEC];        // element offset of this thread's v-th float4 inside the image, -1 = zero fill
+#pragma unroll
+    for (int v = 0; v < PVEC; ++v) {
+        const int idx = tid + v * NTHR;
+        const int pix = idx >> 3, c4 = idx & 7;
+        const int py = pix / PW, px = pix - py * PW;
+        const int gy = gy0 + py, gx = gx0 + px;
+        const bool ok = idx < PH * PW * 8 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        poff[v] = ok ? (gy * p.W + gx) * p.in_cs + c4 * 4 : -1;
+    }
+    f32x4 preg[PVEC];
+    auto patch_fetch = [&](int chunk) {
+#pragma unroll
+        for (int v = 0; v < PVEC; ++v) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (poff[v] >= 0) val = *(const f32x4*)(inb + poff[v] + chunk * CK);
+            preg[v] = val;
+        }
+    };
+    auto patch_commit = [&]() {
+#pragma unroll
+        for (int v = 0; v < PVEC; ++v) {
+            const int idx = tid + v * NTHR;
+            if (idx < PH * PW * 8) *(f32x4*)(patch + (idx >> 3) * LDA + (idx & 7) * 4) = preg[v];
+        }
+    };
+
+    // ---- software pipeline -----------------------------------------------------------------------
+    // flattened step it = chunk*TAPS + tap.  Weight tile W(it) lives in wbuf[it % 3] and gets there by
+    // LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write):
+    //   mid step it      : ONE barrier (its vmcnt(0) retires the DMA of W(it+1), issued one step earlier;
+    //                      it also proves every wave left step it-1, so wbuf[(it+2)%3] is free)
+    //   right after it   : issue the DMA of W(it+2)
+    //   end of step it   : A/B fragments of step it+1, group 0 are read ahead into registers
+    // The input patch is single-buffered: at a chunk boundary (once per k*k steps) two barriers bracket
+    // its re-fill; its global loads are issued after the mid barrier of the chunk's last step.
+    const int nchunks = p.Cin / CK;
+    const int total = nchunks * TAPS;
+    constexpr int NWAVES = NTHR / 64;
+    const int wave_u = HP3D_READFIRSTLANE(wave);
+    auto w_dma = [&](int it2, float* dstbuf) {
+        const int ch = it2 / TAPS, tp = it2 - ch * TAPS;
 #pragma unroll
         for (int v = 0; v < C::WVEC; ++v) {
-            const int idx = tid + v * NTHR;          // float4 index inside the [CK x BN] tap tile
-            const int g = idx / (BN * 2);            // 8-channel group (BN*8 floats = BN*2 float4 each)
+            const int pc = v * NWAVES + wave_u;          // 1-KB piece of the [CK x BN] tile
+            const int idx = pc * 64 + lane;              // this lane's float4
+            const int g = idx / (BN * 2);
             const int off = idx - g * (BN * 2);
-            const float* src = p.wpk + (((size_t)tap * C8 + (chunk * 4 + g)) * CO32 + (n0 >> 5)) * 256 + off * 4;
-            wreg[v] = *(const f32x4*)src;
+            const float* src = p.wpk + (((size_t)tp * C8 + (ch * 4 + g)) * CO32 + (n0 >> 5)) * 256 + off * 4;
+            HP3D_GLDS16(src, dstbuf + pc * 256, lane);
         }
     };
-    auto w_commit = [&](float* dst) {
+    f32x4 fa[2][MT], fb[2][NT];
+    auto load_frags = [&](int set, int toff, int g, const float* wb) {
 #pragma unroll
-        for (int v = 0; v < C::WVEC; ++v) *(f32x4*)(dst + (tid + v * NTHR) * 4) = wreg[v];
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *(const f32x4*)(patch + abase[mt] + toff + g * 8);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            fb[set][nt] = *(const f32x4*)(wb + g * (BN * 8) + (wn * NT + nt) * 256 + lane * 4);
     };
-
-    const int nchunks = p.Cin / CK;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();   // everyone is done with the previous chunk's patch and weight buffers
-        // ---- stage the input patch for channels [chunk*32, chunk*32+32) ------------------
-        for (int idx = tid; idx < PH * PW * 8; idx += NTHR) {
-            const int pix = idx >> 3, c4 = idx & 7;
-            const int py = pix / PW, px = pix - py * PW;
-            const int gy = gy0 + py, gx = gx0 + px;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W)
-                v = *(const f32x4*)(inb + ((size_t)gy * p.W + gx) * p.in_cs + chunk * CK + c4 * 4);
-            *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
-        }
-        w_fetch(0, chunk);
-        w_commit(wbuf);
-        __syncthreads();
-
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const float* wb = wbuf + (tap & 1) * C::WBUF_FLOATS;
-            if (tap + 1 < TAPS) w_fetch(tap + 1, chunk);       // in flight during the MFMAs below
-            const int r = tap / KS, s = tap - r * KS;
-            const int toff = (r * PW + s) * LDA;
+    auto mfma_group = [&](int set) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 a[MT], bf[NT];
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) a[mt] = *(const f32x4*)(patch + abase[mt] + toff + g * 8);
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    bf[nt] = *(const f32x4*)(wb + g * (BN * 8) + (wn * NT + nt) * 256 + lane * 4);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt)
-                            acc[mt][nt] = HP3D_MFMA_32x32x2(a[mt][j], bf[nt][j], acc[mt][nt]);
-            }
-            if (tap + 1 < TAPS) {
-                w_commit(wbuf + ((tap + 1) & 1) * C::WBUF_FLOATS);
-                __syncthreads();
-            }
+                    acc[mt][nt] = HP3D_MFMA_32x32x2(fa[set][mt][j], fb[set][nt][j], acc[mt][nt]);
+    };
+    auto tap_off = [&](int tap) {
+        const int r = tap / KS, s = tap - r * KS;
+        return (r * PW + s) * LDA;
+    };
+
+    patch_fetch(0);
+    patch_commit();
+    w_dma(0, wbuf);
+    if (total > 1) w_dma(1, wbuf + C::WBUF_FLOATS);
+    HP3D_WAIT_VMCNT0();
+    __syncthreads();
+    load_frags(0, tap_off(0), 0, wbuf);
+
+    int tap = 0, chunk = 0, buf = 0;   // buf = it % 3
+    for (int it = 0; it < total; ++it) {
+        const float* wb = wbuf + buf * C::WBUF_FLOATS;
+        const int buf1 = (buf == 2) ? 0 : buf + 1;
+        const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+        const bool chunk_end = (tap + 1 == TAPS);
+        const bool has_next = (it + 1 < total);
+        const int toff = tap_off(tap);
+        load_frags(1, toff, 1, wb);
+        mfma_group(0);
+        load_frags(0, toff, 2, wb);
+        mfma_group(1);
+        HP3D_SCHED_BARRIER();
+        // hipcc (ROCm 7.2) does NOT carry a pending LDS-DMA across the loop back-edge into the barrier's
+        // wait: retire this wave's DMA of W(it+1) explicitly before the rendezvous.
+        HP3D_WAIT_VMCNT0();
+        __syncthreads();
+        if (it + 2 < total) w_dma(it + 2, wbuf + buf2 * C::WBUF_FLOATS);
+        if (chunk_end && has_next) patch_fetch(chunk + 1);
+        HP3D_SCHED_BARRIER();
+        load_frags(1, toff, 3, wb);
+        mfma_group(0);
+        if (has_next && !chunk_end) load_frags(0, tap_off(tap + 1), 0, wbuf + buf1 * C::WBUF_FLOATS);
+        mfma_group(1);
+        HP3D_SCHED_BARRIER();
+        if (chunk_end && has_next) {
+            __syncthreads();          // every wave is done reading this chunk's patch
+            patch_commit();
+            __syncthreads();
+            load_frags(0, tap_off(0), 0, wbuf + buf1 * C::WBUF_FLOATS);
         }
+        buf = buf1;
+        if (chunk_end) { tap = 0; ++chunk; } else { ++tap; }
     }
 
     // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store ------------------------
@@ -200,14 +260,21 @@ int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
     case id: {                                                                                       \
         using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;                                        \
         auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, WM, WN, MT, NT, POOL>;                       \
-        static bool attr_done = false;                                                               \
+        static bool attr_done = false, attr_done2 = false;                                          \
         if (!attr_done) {                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 C::SMEM_BYTES);                                                      \
             attr_done = true;                                                                        \
         }                                                                                            \
         dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN);                                      \
-        HP3D_LAUNCH(kern, grid, dim3(C::NTHR), C::SMEM_BYTES, s, p);                                 \
+        ConvParams pp = p; pp.dbg = 0;                                                               \
+        static int extra_lds = getenv("HP3D_CONV_EXTRA_LDS") ? atoi(getenv("HP3D_CONV_EXTRA_LDS")) : 0; \
+        if (extra_lds && !attr_done2) {                                                              \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                C::SMEM_BYTES + extra_lds);                                          \
+            attr_done2 = true;                                                                       \
+        }                                                                                            \
+        HP3D_LAUNCH(kern, grid, dim3(C::NTHR), C::SMEM_BYTES + extra_lds, s, pp);                    \
         return 0;                                                                                    \
     }
     switch (cfg) {
@@ -245,6 +312,11 @@ int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cout, int pool, int B,
     plan->tw = wide ? 16 : 8;
     plan->bn = bn;
     plan->variant = (wide ? 0 : 3) + (bn == 128 ? 0 : bn == 64 ? 1 : 2);
+    // tuning knob (benchmarks only): HP3D_CONV_CFG=<0..5> forces a tile config when it divides Cout
+    static int force = getenv("HP3D_CONV_CFG") ? atoi(getenv("HP3D_CONV_CFG")) : -1;
+    if (force >= 0 && force <= 5 && Cout % kCfgBN[force] == 0 && Cout >= 64) {
+        plan->variant = force; plan->tw = kCfgTW[force]; plan->bn = kCfgBN[force];
+    }
     return 0;
 }
 

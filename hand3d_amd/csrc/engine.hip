@@ -392,7 +392,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = l.relu;
+        p.act = l.relu; p.dbg = 0;
         ProfScope ps(ctx, l.name, conv_mfma_variant_name(k, l.stride, pool, plan), flops, bytes);
         if (conv_mfma_launch(p, k, l.stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed for %s", l.name.c_str());
@@ -1048,7 +1048,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = act;
+        p.act = act; p.dbg = 0;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");
     }

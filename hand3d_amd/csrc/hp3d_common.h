@@ -18,6 +18,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 #define HP3D_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
+#define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define HP3D_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
+#define HP3D_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+// LDS-DMA: each lane copies 16 B from its own global address to (wave-uniform LDS base) + lane*16
+#define HP3D_GLDS16(gptr, lds_wave_base, lane)                                                     \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
+                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
 #endif
 
 #include <stdint.h>
@@ -39,6 +46,7 @@ struct ConvParams {
     int pad_t, pad_l;     // TF SAME "before" padding
     int tiles_x, tiles_y; // spatial tiles per image
     int act;              // HP3D_ACT_*
+    int dbg;              // timing-ablation bits (HP3D_CONV_DBG, benchmarks only; 0 in production)
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------

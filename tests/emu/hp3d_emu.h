@@ -36,6 +36,10 @@ extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define HP3D_KERNEL(nthr)
+#define HP3D_SCHED_BARRIER() ((void)0)
+#define HP3D_READFIRSTLANE(x) (x)
+#define HP3D_WAIT_VMCNT0() ((void)0)
+#define HP3D_GLDS16(gptr, lds_wave_base, lane) memcpy((float*)(lds_wave_base) + (lane) * 4, (gptr), 16)
 extern float* hp3d_emu_smem;
 #define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem
 

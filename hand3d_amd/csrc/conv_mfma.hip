@@ -125,37 +125,46 @@ void conv_mfma_kernel(const ConvParams p) {
     };
 
     // ---- software pipeline -----------------------------------------------------------------------
-    // flattened step it = chunk*TAPS + tap.  Weight tile W(it) lives in wbuf[it % 3] and gets there by
-    // LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write):
-    //   mid step it      : ONE barrier (its vmcnt(0) retires the DMA of W(it+1), issued one step earlier;
-    //                      it also proves every wave left step it-1, so wbuf[(it+2)%3] is free)
+    // step it = chunk*TAPS + tap.  Weight tile W(it) lives in wbuf[it % 3] and gets there by LDS-DMA
+    // (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write; the per-step part of the source
+    // address is ONE scalar offset, the per-lane part a loop-invariant VGPR -> zero VALU per DMA):
+    //   mid step it      : ONE barrier (the explicit vmcnt(0) before it retires the DMA of W(it+1), issued
+    //                      one step earlier; it also proves every wave left step it-1: wbuf[(it+2)%3] is free)
     //   right after it   : issue the DMA of W(it+2)
     //   end of step it   : A/B fragments of step it+1, group 0 are read ahead into registers
     // The input patch is single-buffered: at a chunk boundary (once per k*k steps) two barriers bracket
     // its re-fill; its global loads are issued after the mid barrier of the chunk's last step.
+    // For 3x3 the nine taps are unrolled (9 % 3 == 0 makes the ring index static too), so every LDS
+    // address in the loop is base-register + immediate.
     const int nchunks = p.Cin / CK;
     const int total = nchunks * TAPS;
     constexpr int NWAVES = NTHR / 64;
+    constexpr int NB = BN / 32;                       // 1-KB pieces per 8-channel group
     const int wave_u = HP3D_READFIRSTLANE(wave);
-    auto w_dma = [&](int it2, float* dstbuf) {
-        const int ch = it2 / TAPS, tp = it2 - ch * TAPS;
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(TAPS * p.Cin) * (unsigned)p.Cout * 4u);
+    const int tap_stride_b = C8 * CO32 * 1024;        // bytes between taps of the packed weights
+    const int chunk_stride_b = 4 * CO32 * 1024;       // bytes between 32-channel chunks
+    const int w_base_b = (n0 >> 5) * 1024;
+    int wvoff[C::WVEC];                               // loop-invariant per-lane byte offsets of this wave's pieces
 #pragma unroll
-        for (int v = 0; v < C::WVEC; ++v) {
-            const int pc = v * NWAVES + wave_u;          // 1-KB piece of the [CK x BN] tile
-            const int idx = pc * 64 + lane;              // this lane's float4
-            const int g = idx / (BN * 2);
-            const int off = idx - g * (BN * 2);
-            const float* src = p.wpk + (((size_t)tp * C8 + (ch * 4 + g)) * CO32 + (n0 >> 5)) * 256 + off * 4;
-            HP3D_GLDS16(src, dstbuf + pc * 256, lane);
-        }
+    for (int v = 0; v < C::WVEC; ++v) {
+        const int pc = v * NWAVES + wave;
+        wvoff[v] = (pc / NB) * (CO32 * 1024) + (pc % NB) * 1024 + lane * 16;
+    }
+    auto w_dma = [&](int tp, int ch, int bufidx) {
+        const int soff = w_base_b + tp * tap_stride_b + ch * chunk_stride_b;          // scalar
+#pragma unroll
+        for (int v = 0; v < C::WVEC; ++v)
+            HP3D_BUFFER_LDS16(wrsrc, wbuf + bufidx * C::WBUF_FLOATS + (v * NWAVES + wave_u) * 256, wvoff[v], soff, lane);
     };
     f32x4 fa[2][MT], fb[2][NT];
-    auto load_frags = [&](int set, int toff, int g, const float* wb) {
+    const int bbase = (wn * NT) * 256 + lane * 4;
+    auto load_frags = [&](int set, int toff, int g, int bufidx) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *(const f32x4*)(patch + abase[mt] + toff + g * 8);
+        for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *(const f32x4*)(patch + abase[mt] + (toff + g * 8));
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-            fb[set][nt] = *(const f32x4*)(wb + g * (BN * 8) + (wn * NT + nt) * 256 + lane * 4);
+            fb[set][nt] = *(const f32x4*)(wbuf + bbase + (bufidx * C::WBUF_FLOATS + g * (BN * 8) + nt * 256));
     };
     auto mfma_group = [&](int set) {
 #pragma unroll
@@ -170,48 +179,61 @@ void conv_mfma_kernel(const ConvParams p) {
         const int r = tap / KS, s = tap - r * KS;
         return (r * PW + s) * LDA;
     };
-
-    patch_fetch(0);
-    patch_commit();
-    w_dma(0, wbuf);
-    if (total > 1) w_dma(1, wbuf + C::WBUF_FLOATS);
-    HP3D_WAIT_VMCNT0();
-    __syncthreads();
-    load_frags(0, tap_off(0), 0, wbuf);
-
-    int tap = 0, chunk = 0, buf = 0;   // buf = it % 3
-    for (int it = 0; it < total; ++it) {
-        const float* wb = wbuf + buf * C::WBUF_FLOATS;
-        const int buf1 = (buf == 2) ? 0 : buf + 1;
-        const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+    // one pipeline step; with constant (tap, buf) after unrolling everything below folds to immediates
+    auto step = [&](int tap, int chunk, int buf, int it) {
+        const int buf1 = (buf + 1) % 3, buf2 = (buf + 2) % 3;
         const bool chunk_end = (tap + 1 == TAPS);
         const bool has_next = (it + 1 < total);
         const int toff = tap_off(tap);
-        load_frags(1, toff, 1, wb);
+        load_frags(1, toff, 1, buf);
         mfma_group(0);
-        load_frags(0, toff, 2, wb);
+        load_frags(0, toff, 2, buf);
         mfma_group(1);
         HP3D_SCHED_BARRIER();
         // hipcc (ROCm 7.2) does NOT carry a pending LDS-DMA across the loop back-edge into the barrier's
         // wait: retire this wave's DMA of W(it+1) explicitly before the rendezvous.
         HP3D_WAIT_VMCNT0();
         __syncthreads();
-        if (it + 2 < total) w_dma(it + 2, wbuf + buf2 * C::WBUF_FLOATS);
+        if (it + 2 < total) {
+            const int tp2 = (tap + 2 < TAPS) ? tap + 2 : tap + 2 - TAPS;     // TAPS == 1: handled below
+            const int ch2 = (tap + 2 < TAPS) ? chunk : chunk + 1;
+            if (TAPS == 1) w_dma(0, chunk + 2, buf2); else w_dma(tp2, ch2, buf2);
+        }
         if (chunk_end && has_next) patch_fetch(chunk + 1);
         HP3D_SCHED_BARRIER();
-        load_frags(1, toff, 3, wb);
+        load_frags(1, toff, 3, buf);
         mfma_group(0);
-        if (has_next && !chunk_end) load_frags(0, tap_off(tap + 1), 0, wbuf + buf1 * C::WBUF_FLOATS);
+        if (has_next && !chunk_end) load_frags(0, tap_off(tap + 1), 0, buf1);
         mfma_group(1);
         HP3D_SCHED_BARRIER();
         if (chunk_end && has_next) {
             __syncthreads();          // every wave is done reading this chunk's patch
             patch_commit();
             __syncthreads();
-            load_frags(0, tap_off(0), 0, wbuf + buf1 * C::WBUF_FLOATS);
+            load_frags(0, tap_off(0), 0, buf1);
         }
-        buf = buf1;
-        if (chunk_end) { tap = 0; ++chunk; } else { ++tap; }
+    };
+
+    patch_fetch(0);
+    patch_commit();
+    w_dma(0, 0, 0);
+    if (total > 1) { if (TAPS == 1) w_dma(0, 1, 1); else w_dma(1, 0, 1); }
+    HP3D_WAIT_VMCNT0();
+    __syncthreads();
+    load_frags(0, tap_off(0), 0, 0);
+
+    if (TAPS % 3 == 0) {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) step(tap, chunk, tap % 3, chunk * TAPS + tap);
+        }
+    } else {
+        int buf = 0, it = 0;
+        for (int chunk = 0; chunk < nchunks; ++chunk)
+            for (int tap = 0; tap < TAPS; ++tap, ++it) {
+                step(tap, chunk, buf, it);
+                buf = (buf == 2) ? 0 : buf + 1;
+            }
     }
 
     // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store ------------------------

@@ -21,10 +21,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define HP3D_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
 #define HP3D_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-// LDS-DMA: each lane copies 16 B from its own global address to (wave-uniform LDS base) + lane*16
-#define HP3D_GLDS16(gptr, lds_wave_base, lane)                                                     \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),       \
-                                     (__attribute__((address_space(3))) void*)(lds_wave_base), 16, 0, 0)
+// buffer-addressed LDS-DMA: 16 B per lane from (rsrc base + per-lane voff + scalar soff) to
+// (wave-uniform LDS base) + lane*16; out-of-range offsets return 0 (hardware bounds check).
+// The builtins exist in the device pass only; hipcc's host pass (which just needs the kernel stubs)
+// sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
+#define HP3D_MAKE_RSRC(ptr, bytes) __builtin_amdgcn_make_buffer_rsrc((void*)(ptr), 0, (bytes), 0x00020000)
+#define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane)                                   \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, \
+                                             (voff), (soff), 0, 0)
+#else
+typedef int hp3d_rsrc_t;
+#define HP3D_MAKE_RSRC(ptr, bytes) 0
+#define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc))
+#endif
 #endif
 
 #include <stdint.h>

@@ -39,6 +39,14 @@ extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu
 #define HP3D_SCHED_BARRIER() ((void)0)
 #define HP3D_READFIRSTLANE(x) (x)
 #define HP3D_WAIT_VMCNT0() ((void)0)
+struct hp3d_rsrc_t { const char* base; unsigned bytes; };
+#define HP3D_MAKE_RSRC(ptr, bytes) hp3d_rsrc_t{(const char*)(ptr), (unsigned)(bytes)}
+static inline void hp3d_emu_buffer_lds16(hp3d_rsrc_t r, float* lds_wave_base, unsigned off, int lane) {
+    if (off + 16u <= r.bytes) memcpy(lds_wave_base + lane * 4, r.base + off, 16);
+    else memset(lds_wave_base + lane * 4, 0, 16);
+}
+#define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) \
+    hp3d_emu_buffer_lds16((rsrc), (float*)(lds_wave_base), (unsigned)(voff) + (unsigned)(soff), (lane))
 #define HP3D_GLDS16(gptr, lds_wave_base, lane) memcpy((float*)(lds_wave_base) + (lane) * 4, (gptr), 16)
 extern float* hp3d_emu_smem;
 #define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem

@@ -130,8 +130,19 @@ def main():
         dom = max(fam, key=lambda k: fam[k][0])
         ms, fl, by, n = fam[dom]
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
+        # scripts/summarize_prof.py -> profiles/conv_mfma_traffic.json); counters cannot be read in-process.
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'conv_mfma_traffic.json')
+        if dom == 'conv_mfma' and a.workload == 'full' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
+            try:
+                traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+            except Exception:
+                traffic = None
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per launch (PMC, profiles/conv_mfma_traffic.json)",
+                "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
                 "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
                 "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                 "share_of_gpu_time": round(ms / max(sum(v[0] for v in fam.values()), 1e-9), 4)}

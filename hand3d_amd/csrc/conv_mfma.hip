@@ -214,8 +214,30 @@ void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
-    patch_fetch(0);
-    patch_commit();
+    if (p.im2col) {
+        // conv1_1 (Cin = 3, utils/general.py:36-53 at nets/ColorHandPose3DNetwork.py:144,183): the A tile is
+        // built straight from the [B,H,W,3] image as K = (r*3+s)*3+c (27 real + 5 zero) -- no im2col
+        // buffer in HBM.  KS == 1 here, so the "patch" is the tile itself.
+        const float* img = p.in + (size_t)b * p.H * p.W * 3;
+        for (int idx = tid; idx < PH * PW * 8; idx += NTHR) {
+            const int pix = idx >> 3, c4 = idx & 7;
+            const int py = pix / PW, px = pix - py * PW;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = c4 * 4 + e;
+                if (k < 27) {
+                    const int tp = k / 3, c = k - tp * 3;
+                    const int iy = gy0 + py + tp / 3 - 1, ix = gx0 + px + tp % 3 - 1;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[e] = img[(iy * p.W + ix) * 3 + c];
+                }
+            }
+            *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
+        }
+    } else {
+        patch_fetch(0);
+        patch_commit();
+    }
     w_dma(0, 0, 0);
     if (total > 1) { if (TAPS == 1) w_dma(0, 1, 1); else w_dma(1, 0, 1); }
     HP3D_WAIT_VMCNT0();
@@ -289,7 +311,7 @@ int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
             attr_done = true;                                                                        \
         }                                                                                            \
         dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN);                                      \
-        ConvParams pp = p; pp.dbg = 0;                                                               \
+        const ConvParams& pp = p;                                                                    \
         static int extra_lds = getenv("HP3D_CONV_EXTRA_LDS") ? atoi(getenv("HP3D_CONV_EXTRA_LDS")) : 0; \
         if (extra_lds && !attr_done2) {                                                              \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \

@@ -201,7 +201,7 @@ struct hp3d_ctx {
           *d_scale = nullptr, *d_cropsize = nullptr, *d_kpmap = nullptr, *d_coord = nullptr, *d_mask = nullptr,
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
           *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
-          *d_pooled = nullptr;
+          *d_pooled = nullptr, *d_fcpart = nullptr;
     int* d_seed = nullptr;
     unsigned long long* d_keys = nullptr;
     unsigned char* d_det = nullptr;
@@ -305,10 +305,6 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->bufB, act));
         ctx->act_floats = act;
     }
-    if (px * 32 > ctx->col_floats) {
-        CHK(dev_realloc(ctx, &ctx->col, px * 32));
-        ctx->col_floats = px * 32;
-    }
     const size_t imgf = (size_t)B * H * W * 3;
     if (imgf > ctx->image_floats) {
         CHK(dev_realloc(ctx, &ctx->d_image, imgf));
@@ -341,6 +337,7 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->d_fcin, (size_t)B * 4100));
         CHK(dev_realloc(ctx, &ctx->d_fc1, (size_t)B * 512));
         CHK(dev_realloc(ctx, &ctx->d_fc2, (size_t)B * 512));
+        CHK(dev_realloc(ctx, &ctx->d_fcpart, (size_t)B * 17 * 512 + (size_t)B * 33 * 256));
         CHK(dev_realloc(ctx, &ctx->d_seed, (size_t)B * 2));
         CHK(dev_realloc(ctx, &ctx->d_keys, (size_t)B));
         ctx->capB = B;
@@ -392,7 +389,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = l.relu; p.dbg = 0;
+        p.act = l.relu; p.im2col = (l.mode == 1);
         ProfScope ps(ctx, l.name, conv_mfma_variant_name(k, l.stride, pool, plan), flops, bytes);
         if (conv_mfma_launch(p, k, l.stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed for %s", l.name.c_str());
@@ -411,15 +408,11 @@ const FcL& FL(hp3d_ctx* ctx, const char* name) { return ctx->T.fc[ctx->T.fc_idx.
 int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H, int W, int n4, float** act, int* h,
               int* w) {
     char nm[64];
-    {
-        ProfScope ps(ctx, std::string(scope) + "/im2col", "im2col3x3", 0.0, 4.0 * B * H * W * (3 + 32));
-        im2col3x3_launch(image, B, H, W, ctx->col, ctx->stream);
-    }
     float* a = ctx->bufA;
     float* b = ctx->bufB;
     int ch = 64, ih = H, iw = W;
     snprintf(nm, sizeof nm, "%s/conv1_1", scope);
-    CHK(run_conv(ctx, CL(ctx, nm), ctx->col, 32, B, ih, iw, a, 64, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, nm), image, 3, B, ih, iw, a, 64, 0, nullptr, nullptr));   // im2col fused in the loader
     const int nl[4] = {2, 2, 4, n4}, chs[4] = {64, 128, 256, 512};
     for (int blk = 0; blk < 4; ++blk) {
         for (int i = (blk == 0 ? 1 : 0); i < nl[blk]; ++i) {
@@ -486,7 +479,7 @@ int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
 int run_fc(hp3d_ctx* ctx, const FcL& l, const float* x, int B, int x_stride, float* out, int out_stride) {
     ProfScope ps(ctx, l.name, "fc", 2.0 * l.cin * l.cout * B, 4.0 * ((double)l.cin * l.cout + (double)B * (l.cin + l.cout)));
     fc_launch(x, B, l.cin, x_stride, ctx->blob + l.w_off, ctx->blob + l.b_off, l.cout, l.relu, out, out_stride,
-              ctx->stream);
+              ctx->d_fcpart, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -737,7 +730,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
                     &ctx->d_crop, &ctx->d_center, &ctx->d_scale, &ctx->d_cropsize, &ctx->d_kpmap, &ctx->d_coord,
                     &ctx->d_mask, &ctx->d_segsmall, &ctx->d_concat, &ctx->d_sm[0], &ctx->d_sm[1], &ctx->d_sm[2],
                     &ctx->d_can, &ctx->d_rot, &ctx->d_u, &ctx->d_fcin, &ctx->d_fc1, &ctx->d_fc2, &ctx->d_fg,
-                    &ctx->d_pooled};
+                    &ctx->d_pooled, &ctx->d_fcpart};
     for (float** p : fp)
         if (*p) hipFree(*p);
     if (ctx->d_seed) hipFree(ctx->d_seed);
@@ -1048,7 +1041,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = act; p.dbg = 0;
+        p.act = act; p.im2col = 0;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");
     }
@@ -1152,7 +1145,8 @@ int hp3d_fc(hp3d_ctx* ctx, const float* x, int B, int Cin, const float* w, const
     float* d_w = S.upload(w, (size_t)Cin * Cout); NN(ctx, d_w);
     float* d_b = S.upload(bias, (size_t)Cout); NN(ctx, d_b);
     float* d_o = S.alloc<float>((size_t)B * Cout); NN(ctx, d_o);
-    fc_launch(d_x, B, Cin, Cin, d_w, d_b, Cout, act, d_o, Cout, ctx->stream);
+    float* d_p = S.alloc<float>(fc_scratch_floats(B, Cin, Cout)); NN(ctx, d_p);
+    fc_launch(d_x, B, Cin, Cin, d_w, d_b, Cout, act, d_o, Cout, d_p, ctx->stream);
     HIPCHK(ctx, hipMemcpyAsync(out, d_o, sizeof(float) * (size_t)B * Cout, hipMemcpyDeviceToHost, ctx->stream));
     return finish_op(ctx);
 }

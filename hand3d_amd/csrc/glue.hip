@@ -385,41 +385,65 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
 
 // ---------------------------------------------------------------------------------------
 // Fully connected: out[b][o] = sum_i x[b][i] * W[i][o] + bias[o]  (utils/general.py:112-136)
-// workgroup = 64 outputs x 4 K-slices, 8 batch rows per pass; W rows are read coalesced.
-constexpr int FC_BB = 8;
+// Weight-streaming bound (4-9 MB of weights, a few MFLOP): split-K over many workgroups so the whole
+// chip streams W once, then a fixed-order reduction (deterministic, no atomics).
+//   pass 1: workgroup = 64 outputs x one 128-row K slice x up to 32 batch rows; 4 K-quarters per
+//           workgroup, x slice staged transposed in LDS, W rows read coalesced (256 B per row).
+//   pass 2: out = act(bias + sum over K slices in index order).
+constexpr int FC_KCH = 128, FC_BT = 32;
 HP3D_KERNEL(256)
-void fc_kernel(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout, int act,
-               float* out, int out_stride) {
-    __shared__ float red[4][FC_BB][64];
+void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float* w, int Cout, float* part) {
+    __shared__ float xs[FC_KCH][FC_BT + 4];        // [k][b], pitch 36 floats (16-B aligned rows)
+    __shared__ float red[4][FC_BT][64];
     const int o = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int ks = threadIdx.x >> 6;
-    const int b0 = blockIdx.y * FC_BB;
-    float acc[FC_BB];
+    const int kq = threadIdx.x >> 6;               // K quarter: rows kq*32 .. kq*32+31 of the slice
+    const int k0 = blockIdx.y * FC_KCH;
+    const int b0 = blockIdx.z * FC_BT;
+    for (int i = threadIdx.x; i < FC_KCH * FC_BT; i += 256) {
+        const int b = i / FC_KCH, kk = i - b * FC_KCH;       // coalesced along k
+        const int gb = b0 + b, gk = k0 + kk;
+        xs[kk][b] = (gb < B && gk < Cin) ? x[(size_t)gb * x_stride + gk] : 0.f;
+    }
+    __syncthreads();
+    float acc[FC_BT];
 #pragma unroll
-    for (int j = 0; j < FC_BB; ++j) acc[j] = 0.f;
+    for (int j = 0; j < FC_BT; ++j) acc[j] = 0.f;
     if (o < Cout) {
-        for (int i = ks; i < Cin; i += 4) {
-            const float wv = w[(size_t)i * Cout + o];
+        for (int kk = kq * 32; kk < kq * 32 + 32; ++kk) {
+            const int gk = k0 + kk;
+            if (gk >= Cin) break;
+            const float wv = w[(size_t)gk * Cout + o];
 #pragma unroll
-            for (int j = 0; j < FC_BB; ++j) {
-                const int b = b0 + j;
-                const float xv = (b < B) ? x[(size_t)b * x_stride + i] : 0.f;
-                acc[j] = fmaf(xv, wv, acc[j]);
+            for (int j4 = 0; j4 < FC_BT / 4; ++j4) {
+                const f32x4 xv = *(const f32x4*)&xs[kk][j4 * 4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j4 * 4 + e] = fmaf(xv[e], wv, acc[j4 * 4 + e]);
             }
         }
     }
 #pragma unroll
-    for (int j = 0; j < FC_BB; ++j) red[ks][j][threadIdx.x & 63] = acc[j];
+    for (int j = 0; j < FC_BT; ++j) red[kq][j][threadIdx.x & 63] = acc[j];
     __syncthreads();
-    if (ks == 0 && o < Cout) {
-#pragma unroll
-        for (int j = 0; j < FC_BB; ++j) {
-            const int b = b0 + j;
-            if (b >= B) break;
-            float v = ((red[0][j][threadIdx.x] + red[1][j][threadIdx.x]) + (red[2][j][threadIdx.x] + red[3][j][threadIdx.x])) + bias[o];
-            if (act) v = leaky(v);
-            out[(size_t)b * out_stride + o] = v;
-        }
+    // 256 threads reduce the 4 quarters for 32 x 64 outputs
+    for (int i = threadIdx.x; i < FC_BT * 64; i += 256) {
+        const int j = i >> 6, oo = i & 63;
+        const int gb = b0 + j, go = blockIdx.x * 64 + oo;
+        if (gb < B && go < Cout)
+            part[((size_t)blockIdx.y * B + gb) * Cout + go] = (red[0][j][oo] + red[1][j][oo]) + (red[2][j][oo] + red[3][j][oo]);
+    }
+}
+
+HP3D_KERNEL(256)
+void fc_reduce_kernel(const float* part, int nslices, int B, int Cout, const float* bias, int act, float* out,
+                      int out_stride) {
+    const int total = B * Cout;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int b = i / Cout, o = i - b * Cout;
+        float v = 0.f;
+        for (int s = 0; s < nslices; ++s) v += part[((size_t)s * B + b) * Cout + o];
+        v += bias[o];
+        if (act) v = leaky(v);
+        out[(size_t)b * out_stride + o] = v;
     }
 }
 
@@ -556,10 +580,14 @@ void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltm
     HP3D_LAUNCH(mask_grow_kernel, dim3(B), dim3(1024), smem, s, (const unsigned char*)mb.det,
                 (const unsigned long long*)mb.argmax_key, H, W, empty_fltmax, mask_out, center, crop_size, scale, seed);
 }
+size_t fc_scratch_floats(int B, int Cin, int Cout) { return (size_t)((Cin + FC_KCH - 1) / FC_KCH) * B * Cout; }
 void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout, int act,
-               float* out, int out_stride, hipStream_t s) {
-    HP3D_LAUNCH(fc_kernel, dim3((Cout + 63) / 64, (B + FC_BB - 1) / FC_BB), dim3(256), 0, s, x, B, Cin, x_stride, w,
-                bias, Cout, act, out, out_stride);
+               float* out, int out_stride, float* scratch, hipStream_t s) {
+    const int ns = (Cin + FC_KCH - 1) / FC_KCH;
+    HP3D_LAUNCH(fc_partial_kernel, dim3((Cout + 63) / 64, ns, (B + FC_BT - 1) / FC_BT), dim3(256), 0, s, x, B, Cin,
+                x_stride, w, Cout, scratch);
+    HP3D_LAUNCH(fc_reduce_kernel, dim3(grid_for((long)B * Cout)), dim3(256), 0, s, (const float*)scratch, ns, B, Cout,
+                bias, act, out, out_stride);
 }
 void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s) {
     HP3D_LAUNCH(concat_handside_kernel, dim3(grid_for((long)B * (F + 2))), dim3(256), 0, s, feat, B, F, hand_side, out);

@@ -57,7 +57,7 @@ struct ConvParams {
     int pad_t, pad_l;     // TF SAME "before" padding
     int tiles_x, tiles_y; // spatial tiles per image
     int act;              // HP3D_ACT_*
-    int dbg;              // timing-ablation bits (HP3D_CONV_DBG, benchmarks only; 0 in production)
+    int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------
@@ -96,8 +96,9 @@ void seg_softmax_launch(const float* scoremap_large, int B, int H, int W, const 
 void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltmax, float* mask_out,
                       float* center, float* crop_size, float* scale, int* seed, hipStream_t s);
 
+size_t fc_scratch_floats(int B, int Cin, int Cout);   // split-K partials [ceil(Cin/128)][B][Cout]
 void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout,
-               int act, float* out, int out_stride, hipStream_t s);
+               int act, float* out, int out_stride, float* scratch, hipStream_t s);
 // [B,4096|2048 feats] + hand_side concat is handled by the executor (copies 2 floats per row)
 void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s);
 // u = (ux,uy,uz) [B,3], coord_can [B,63], hand_side [B,2] -> rot [B,9], coord_rel [B,63]

@@ -17,7 +17,7 @@ from collections import defaultdict
 def family(name):
     if 'conv_mfma_kernel' in name:
         return 'conv_mfma'
-    for k in ('fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
+    for k in ('fc_partial', 'fc_reduce', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
               'copy_channels', 'concat_handside', 'lift_epilogue', 'avgpool8', 'pad_channels'):
         if k in name:
             return k
@@ -83,6 +83,10 @@ def main():
             rdb = 2.0 * fetch['conv_mfma'][0] * 1024 / fetch['conv_mfma'][1]
             wtb = write['conv_mfma'][0] * 1024 / write['conv_mfma'][1] if write['conv_mfma'][1] else 0
             lines.append('conv_mfma HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
+            json.dump({"kernel": "conv_mfma", "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
+                       "workload": bench.get('config', {}).get('workload')},
+                      open(os.path.join(dst, 'conv_mfma_traffic.json'), 'w'), indent=1)
     open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 

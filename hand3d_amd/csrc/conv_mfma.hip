@@ -72,7 +72,12 @@ void conv_mfma_kernel(const ConvParams p) {
     const int gy0 = oy0 * STRIDE - p.pad_t, gx0 = ox0 * STRIDE - p.pad_l;   // patch origin (input coords)
 
     const int C8 = p.Cin >> 3, CO32 = p.Cout >> 5;
-    const float* inb = p.in + (size_t)b * p.H * p.W * p.in_cs;
+    // split-K (under-filled chip, small batch): workgroup z contracts chunks [cbeg, cend) only and
+    // writes raw partial sums; conv_splitk_reduce adds them in z order (+ bias, activation)
+    const int nc_all = p.Cin / CK;
+    const int kz = blockIdx.z;
+    const int cbeg = (kz * nc_all) / p.ksplit, cend = ((kz + 1) * nc_all) / p.ksplit;
+    const float* inb = p.in + (size_t)b * p.H * p.W * p.in_cs + cbeg * CK;
 
     // ---- per-lane A fragment base offsets ---------------------------------------------
     const int li = lane & 31, lh = lane >> 5;
@@ -136,7 +141,7 @@ void conv_mfma_kernel(const ConvParams p) {
     // its re-fill; its global loads are issued after the mid barrier of the chunk's last step.
     // For 3x3 the nine taps are unrolled (9 % 3 == 0 makes the ring index static too), so every LDS
     // address in the loop is base-register + immediate.
-    const int nchunks = p.Cin / CK;
+    const int nchunks = cend - cbeg;
     const int total = nchunks * TAPS;
     constexpr int NWAVES = NTHR / 64;
     constexpr int NB = BN / 32;                       // 1-KB pieces per 8-channel group
@@ -144,7 +149,7 @@ void conv_mfma_kernel(const ConvParams p) {
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(TAPS * p.Cin) * (unsigned)p.Cout * 4u);
     const int tap_stride_b = C8 * CO32 * 1024;        // bytes between taps of the packed weights
     const int chunk_stride_b = 4 * CO32 * 1024;       // bytes between 32-channel chunks
-    const int w_base_b = (n0 >> 5) * 1024;
+    const int w_base_b = (n0 >> 5) * 1024 + cbeg * chunk_stride_b;
     int wvoff[C::WVEC];                               // loop-invariant per-lane byte offsets of this wave's pieces
 #pragma unroll
     for (int v = 0; v < C::WVEC; ++v) {
@@ -260,6 +265,23 @@ void conv_mfma_kernel(const ConvParams p) {
 
     // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store ------------------------
     const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
+    if (p.ksplit > 1) {      // raw partial sums, dense [z][B*Ho*Wo][Cout]
+        float* pb = p.partial + ((size_t)kz * p.B + b) * p.Ho * p.Wo * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int co = n0 + (wn * NT + nt) * 32 + li;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = 2 * (r >> 2) + lh;
+                    const int y = oy0 + (wm * MT + mt) * ROWS_PER_MT + 2 * (q / QX) + ((r >> 1) & 1);
+                    const int x = ox0 + 2 * (q % QX) + (r & 1);
+                    if (y < p.Ho && x < p.Wo) pb[((size_t)y * p.Wo + x) * p.Cout + co] = acc[mt][nt][r];
+                }
+        }
+        return;
+    }
     float* outb = p.out + (size_t)b * Hs * Ws * p.out_cs;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -310,7 +332,7 @@ int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
                                 C::SMEM_BYTES);                                                      \
             attr_done = true;                                                                        \
         }                                                                                            \
-        dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN);                                      \
+        dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN, p.ksplit);                            \
         const ConvParams& pp = p;                                                                    \
         static int extra_lds = getenv("HP3D_CONV_EXTRA_LDS") ? atoi(getenv("HP3D_CONV_EXTRA_LDS")) : 0; \
         if (extra_lds && !attr_done2) {                                                              \
@@ -339,22 +361,32 @@ const int kCfgBN[6] = {128, 64, 32, 128, 64, 32};
 
 }  // namespace
 
-int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cout, int pool, int B, ConvPlan* plan) {
+int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cin, int Cout, int pool, int B, ConvPlan* plan) {
     if (!((k == 1 && stride == 1) || (k == 3 && (stride == 1 || stride == 2)) || (k == 7 && stride == 1))) return -1;
-    if (Cout % 32) return -1;
+    if (Cout % 32 || Cin % 32) return -1;
     if (pool && !(k == 3 && stride == 1)) return -1;
-    const int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : 32;
+    int bn = (Cout % 128 == 0) ? 128 : (Cout % 64 == 0) ? 64 : 32;
     auto cdiv = [](int a, int b) { return (a + b - 1) / b; };
     // padded pixels computed by each tiling; prefer the wider tile unless it wastes >12% more
     const long px16 = (long)cdiv(Ho, 8) * 8 * cdiv(Wo, 16) * 16;
     const long px8 = (long)cdiv(Ho, 8) * 8 * cdiv(Wo, 8) * 8;
     bool wide = (double)px16 <= 1.12 * (double)px8;
-    // under-filled chip: more, smaller workgroups
+    // under-filled chip (256 CUs, 2 workgroups each): more, smaller workgroups
     const long blocks16 = (long)B * cdiv(Ho, 8) * cdiv(Wo, 16) * (Cout / bn);
     if (blocks16 < 512) wide = false;
+    long blocks = (long)B * cdiv(Ho, 8) * cdiv(Wo, wide ? 16 : 8) * (Cout / bn);
+    while (blocks < 256 && bn > 32) { bn >>= 1; blocks <<= 1; }       // narrower cout tiles
+    int ksplit = 1;
+    const int nch = Cin / 32;
+    if (!pool && blocks < 256 && nch > 1) {                            // still under-filled: split K
+        ksplit = (int)((256 + blocks - 1) / blocks);
+        if (ksplit > nch) ksplit = nch;
+        if (ksplit > 16) ksplit = 16;
+    }
     plan->th = 8;
     plan->tw = wide ? 16 : 8;
     plan->bn = bn;
+    plan->ksplit = ksplit;
     plan->variant = (wide ? 0 : 3) + (bn == 128 ? 0 : bn == 64 ? 1 : 2);
     // tuning knob (benchmarks only): HP3D_CONV_CFG=<0..5> forces a tile config when it divides Cout
     static int force = getenv("HP3D_CONV_CFG") ? atoi(getenv("HP3D_CONV_CFG")) : -1;
@@ -376,11 +408,12 @@ int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const Con
 }
 
 const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan) {
-    static char buf[6 * 5 * 2][48];
+    static char buf[6 * 5 * 3][48];
     static const int ks[5] = {1, 3, 3, 7, 3};
     int kid = (k == 1) ? 0 : (k == 3 && stride == 1) ? 1 : (k == 3 && stride == 2) ? 2 : 3;
     (void)ks;
-    char* b = buf[(plan.variant * 5 + kid) * 2 + (pool ? 1 : 0)];
-    snprintf(b, 48, "conv_mfma_k%ds%d_t%dx%d_n%d%s", k, stride, plan.th, plan.tw, plan.bn, pool ? "_pool" : "");
+    char* b = buf[(plan.variant * 5 + kid) * 3 + (pool ? 1 : plan.ksplit > 1 ? 2 : 0)];
+    snprintf(b, 48, "conv_mfma_k%ds%d_t%dx%d_n%d%s", k, stride, plan.th, plan.tw, plan.bn,
+             pool ? "_pool" : plan.ksplit > 1 ? "_splitk" : "");
     return b;
 }

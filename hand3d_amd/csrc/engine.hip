@@ -380,8 +380,17 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                           l.relu, out, out_cs, Ho, Wo, pt, pl, ctx->stream);
     } else {
         ConvPlan plan;
-        if (conv_mfma_plan(k, l.stride, Ho, Wo, l.cout_pad, pool, B, &plan) != 0)
+        if (conv_mfma_plan(k, l.stride, Ho, Wo, l.cin_pad, l.cout_pad, pool, B, &plan) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no conv_mfma variant for %s (k=%d s=%d)", l.name.c_str(), k, l.stride);
+        if (l.mode == 1) plan.ksplit = 1;
+        if (plan.ksplit > 1) {
+            const size_t need = (size_t)plan.ksplit * B * Ho * Wo * l.cout_pad;
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+        }
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + l.w_off; p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -390,9 +399,13 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
         p.act = l.relu; p.im2col = (l.mode == 1);
+        p.ksplit = plan.ksplit; p.partial = ctx->col;
         ProfScope ps(ctx, l.name, conv_mfma_variant_name(k, l.stride, pool, plan), flops, bytes);
         if (conv_mfma_launch(p, k, l.stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed for %s", l.name.c_str());
+        if (plan.ksplit > 1)
+            conv_splitk_reduce_launch(ctx->col, plan.ksplit, (long)B * Ho * Wo, l.cout_pad, p.bias, l.relu, out, out_cs,
+                                      p.cout_store, ctx->stream);
     }
     HIPCHK(ctx, hipGetLastError());
     if (Ho_out) *Ho_out = pool ? Ho / 2 : Ho;
@@ -1033,8 +1046,10 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     } else {
         float* d_pk = S.upload(packed.data(), packed.size()); NN(ctx, d_pk);
         ConvPlan plan;
-        if (conv_mfma_plan(k, stride, Ho, Wo, l.cout_pad, pool, B, &plan) != 0)
+        if (conv_mfma_plan(k, stride, Ho, Wo, l.cin_pad, l.cout_pad, pool, B, &plan) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no conv_mfma variant for k=%d stride=%d pool=%d", k, stride, pool);
+        float* d_part = nullptr;
+        if (plan.ksplit > 1) { d_part = S.alloc<float>((size_t)plan.ksplit * B * Ho * Wo * l.cout_pad); NN(ctx, d_part); }
         ConvParams p;
         p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + l.b_off; p.out = d_out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -1042,8 +1057,12 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
         p.act = act; p.im2col = 0;
+        p.ksplit = plan.ksplit; p.partial = d_part;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");
+        if (plan.ksplit > 1)
+            conv_splitk_reduce_launch(d_part, plan.ksplit, (long)B * Ho * Wo, l.cout_pad, p.bias, act, d_out, Cout, Cout,
+                                      ctx->stream);
     }
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));

@@ -40,6 +40,22 @@ void conv_naive_kernel(const float* x, int B, int H, int W, int Cin, int in_cs, 
     }
 }
 
+// split-K epilogue of conv_mfma: fixed-order sum over the K slices, then bias + leaky-ReLU
+HP3D_KERNEL(256)
+void conv_splitk_reduce_kernel(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
+                               float* out, int out_cs, int cout_store) {
+    const long total = npix * cout_store;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_store);
+        const long pix = i / cout_store;
+        float v = 0.f;
+        for (int z = 0; z < ksplit; ++z) v += partial[((size_t)z * npix + pix) * Cout + co];
+        v += bias[co];
+        if (act) v = leaky(v);
+        out[pix * out_cs + co] = v;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // im2col3x3: image [B,H,W,3] -> [B,H,W,32] with channel (r*3+s)*3+c = img[y+r-1][x+s-1][c]
 // (zero outside, channels 27..31 zero).  conv1_1 (Cin=3) then runs as a 1x1 MFMA conv with K=32.
@@ -525,6 +541,11 @@ void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, 
                        int pad_l, hipStream_t s) {
     HP3D_LAUNCH(conv_naive_kernel, dim3(grid_for((long)B * Ho * Wo * Cout)), dim3(256), 0, s, x, B, H, W, Cin, in_cs,
                 w, bias, k, stride, Cout, act, out, out_cs, Ho, Wo, pad_t, pad_l);
+}
+void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
+                               float* out, int out_cs, int cout_store, hipStream_t s) {
+    HP3D_LAUNCH(conv_splitk_reduce_kernel, dim3(grid_for(npix * cout_store)), dim3(256), 0, s, partial, ksplit, npix,
+                Cout, bias, act, out, out_cs, cout_store);
 }
 void im2col3x3_launch(const float* img, int B, int H, int W, float* out32, hipStream_t s) {
     HP3D_LAUNCH(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 32)), dim3(256), 0, s, img, B, H, W, out32);

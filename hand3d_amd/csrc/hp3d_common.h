@@ -57,6 +57,8 @@ struct ConvParams {
     int pad_t, pad_l;     // TF SAME "before" padding
     int tiles_x, tiles_y; // spatial tiles per image
     int act;              // HP3D_ACT_*
+    int ksplit;           // >1: split-K over grid.z, raw partial sums go to `partial`
+    float* partial;       // [ksplit][B*Ho*Wo][Cout]
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
 };
 
@@ -64,8 +66,12 @@ struct ConvParams {
 struct ConvPlan {      // chosen by conv_mfma_plan() from the layer geometry
     int th, tw, bn;    // spatial tile (output pixels) and cout tile
     int variant;       // index into the instantiation table
+    int ksplit;        // >1: split the Cin chunks over grid.z (under-filled chip)
 };
-int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cout, int pool, int B, ConvPlan* plan);
+int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cin, int Cout, int pool, int B, ConvPlan* plan);
+// out[pix][co] = act(bias[co] + sum_z partial[z][pix][co]) for co < cout_store
+void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
+                               float* out, int out_cs, int cout_store, hipStream_t s);
 int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s);
 const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan);
 

@@ -301,10 +301,13 @@ def test_full_pipeline_batch_and_2d(net, synth_weights):
     hs = synth.hand_sides(4)
     o = net.inference(img, hs, True)
     assert [a.shape for a in o] == [(4, 240, 320, 2), (4, 256, 256, 3), (4, 1), (4, 2), (4, 256, 256, 21), (4, 21, 3)]
+    # B=1 takes the small-batch plan (narrower cout tiles, split-K): same math, different summation
+    # order -> equal to rounding, with identical discrete decisions (centre, scale)
     for i in range(4):
         oi = net.inference(img[i:i + 1], hs[i:i + 1], True)
+        assert np.array_equal(o[3][i:i + 1], oi[3]) and np.array_equal(o[2][i:i + 1], oi[2])
         for a, b in zip(o, oi):
-            assert np.array_equal(a[i:i + 1], b), "batched result differs from single-image result"
+            assert np.abs(a[i:i + 1] - b).max() < 2e-5, "batched result differs from single-image result"
     kp, crop, scale, center = net.inference2d(img)
     assert np.array_equal(kp, o[4]) and np.array_equal(crop, o[1]) and np.array_equal(scale, o[2]) and np.array_equal(center, o[3])
     ref = N.inference(synth_weights, img, hs, True, acc=np.float64)

@@ -62,12 +62,18 @@ def cpu_baseline(weights, H, W, n_images, workload):
 
 def main():
     a = parse()
+    # keep stdout for the ONE JSON line: route everything else (RCCL's version banner, library chatter)
+    # written to fd 1 during the run to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch
     import torch.distributed as dist
-    if world > 1:
+    use_dist = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ   # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local)
         dist.init_process_group('nccl', rank=rank, world_size=world,
@@ -103,17 +109,17 @@ def main():
     for _ in range(a.warmup):
         step()
     eng.set_profiling(2)   # HIP events on the engine stream around every launch, accumulated over the K steps
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -174,8 +180,8 @@ def main():
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
+    if use_dist:
         dist.destroy_process_group()
 
 

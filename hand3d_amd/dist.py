@@ -22,7 +22,7 @@ def shard_sizes(n_items, world):
 def broadcast_blob(blob_tensor, src=0, group=None):
     """In-place broadcast of the packed weight blob (a flat torch tensor on the rank's device)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.broadcast(blob_tensor, src=src, group=group)
     return blob_tensor
 
@@ -32,7 +32,7 @@ def gather_keypoints(local_kp, n_total=None, group=None):
     the result; rank 0 is the consumer).  Ragged shards are padded to the largest shard."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_kp
     world = dist.get_world_size(group)
     if n_total is None:
@@ -64,7 +64,8 @@ class ShardedPipeline(object):
         if self.rank == 0:
             self.engine.load_weight_dict(weights)
             self.engine.finalize_weights()
-        if self.world == 1:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
             return
         n = self.engine.blob_bytes() // 4
         blob = torch.empty(n, dtype=torch.float32, device=device)
@@ -72,6 +73,6 @@ class ShardedPipeline(object):
             self.engine.blob_export(blob.data_ptr())
         broadcast_blob(blob, 0, self.group)
         torch.cuda.synchronize(device)
-        if self.rank != 0:
+        if self.rank != 0 or self.world == 1:     # world 1 (torchrun with one rank) re-imports its own blob: exercises the path
             self.engine.blob_import(blob.data_ptr(), full)
         del blob

@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, 'libhp3d.so')
 
-VARIANTS = {'direct': 0, 'bottleneck': 1, 'proposed': 2}
+VARIANTS = {'direct': 0, 'bottleneck': 1, 'proposed': 2, 'local': 3, 'local_w_xyz_loss': 3}
 NET_SEG, NET_POSE, NET_PRIOR, NET_VP, NET_BOTTLENECK = 1, 2, 4, 8, 16
 
 _f = C.POINTER(C.c_float)
@@ -36,6 +36,8 @@ _SIGNATURES = {
     'hp3d_nets_mask': (C.c_int, [_ctx]),
     'hp3d_infer_full': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
     'hp3d_infer_full_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
+    'hp3d_infer_full_u8': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
+    'hp3d_preprocess_u8': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'hp3d_infer_2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     'hp3d_handsegnet': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3),
     'hp3d_posenet2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
@@ -188,6 +190,28 @@ class Engine(object):
                                            _ptr(o['coord3d']), _ptr(o['mask'])))
         return o
 
+    def infer_full_u8(self, image_u8, hand_side, H=240, W=320, want_mask=False):
+        """uint8 frames [B,Hin,Win,3] -> normalise + resize on device -> full pipeline."""
+        img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+        hand_side = _f32(hand_side)
+        assert img.ndim == 4 and img.shape[3] == 3, "image must be [B,Hin,Win,3] uint8"
+        B, Hin, Win, _ = img.shape
+        o = {'scoremap': np.empty((B, H, W, 2), np.float32), 'crop': np.empty((B, 256, 256, 3), np.float32),
+             'scale': np.empty((B, 1), np.float32), 'center': np.empty((B, 2), np.float32),
+             'kpmap': np.empty((B, 256, 256, 21), np.float32), 'coord3d': np.empty((B, 21, 3), np.float32),
+             'mask': np.empty((B, H, W), np.float32) if want_mask else None}
+        self._chk(self.lib.hp3d_infer_full_u8(self.h, B, Hin, Win, _ptr(img), H, W, _ptr(hand_side), _ptr(o['scoremap']),
+                                              _ptr(o['crop']), _ptr(o['scale']), _ptr(o['center']), _ptr(o['kpmap']),
+                                              _ptr(o['coord3d']), _ptr(o['mask'])))
+        return o
+
+    def preprocess_u8(self, image_u8, H, W):
+        img = np.ascontiguousarray(image_u8, dtype=np.uint8)
+        B, Hin, Win, _ = img.shape
+        out = np.empty((B, H, W, 3), np.float32)
+        self._chk(self.lib.hp3d_preprocess_u8(self.h, _ptr(img), B, Hin, Win, H, W, _ptr(out)))
+        return out
+
     def infer_full_dev(self, B, H, W, image_ptr, hand_side_ptr, scoremap=0, crop=0, scale=0, center=0, kpmap=0,
                        coord3d=0, mask=0):
         """Device-pointer variant (ints); stream-ordered, call sync() before reading."""
@@ -224,8 +248,6 @@ class Engine(object):
         return outs
 
     def poseprior(self, variant, scoremap256, hand_side):
-        if variant in ('local', 'local_w_xyz_loss'):
-            raise NotImplementedError("variant %r needs bone_rel_trafo_inv (SURVEY.md 8f N3)" % variant)
         assert variant in VARIANTS, "Unknown variant."
         sm, hs = _f32(scoremap256), _f32(hand_side)
         assert sm.ndim == 4 and sm.shape[1:] == (256, 256, 21), "scoremap must be [B,256,256,21]"

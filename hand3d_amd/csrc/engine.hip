@@ -205,6 +205,8 @@ struct hp3d_ctx {
     int* d_seed = nullptr;
     unsigned long long* d_keys = nullptr;
     unsigned char* d_det = nullptr;
+    unsigned char* d_u8 = nullptr;
+    size_t u8_bytes = 0;
     size_t image_floats = 0, large_floats = 0, det_bytes = 0, pose_px = 0;
 
     // profiling
@@ -553,7 +555,10 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
     CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
     const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
     if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
-    lift_epilogue_launch(ctx->d_u, ctx->d_can, hs, B, ctx->d_rot, ctx->d_coord, do_rot, ctx->stream);
+    if (variant == HP3D_VARIANT_LOCAL)     // bone_rel_trafo_inv (nets/PosePriorNetwork.py:70-75)
+        bone_rel_inv_launch(ctx->d_can, B, ctx->d_coord, ctx->stream);
+    else
+        lift_epilogue_launch(ctx->d_u, ctx->d_can, hs, B, ctx->d_rot, ctx->d_coord, do_rot, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -608,9 +613,10 @@ int run_detect_and_crop(hp3d_ctx* ctx, const float* d_image, int B, int H, int W
 
 int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                     float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
-                    float* coord3d, float* hand_mask, bool dev) {
+                    float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
+                    int Win = 0) {
     if (!ctx) return HP3D_ERR_ARG;
-    if (!image || !hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
+    if ((!image && !image_u8) || !hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
     CHK(check_img(ctx, B, H, W));
     CHK(need_nets(ctx, NET_SEG | NET_POSE | NET_PRIOR | NET_VP));
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -618,7 +624,15 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
     if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     const float* d_img = image;
     const float* d_hs = hand_side;
-    if (!dev) {
+    if (image_u8) {          // uint8 frame in, x/255-0.5 + resize to the net size on device
+        if (Hin < 2 || Win < 2) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad uint8 frame size %dx%d", Hin, Win);
+        const size_t nb = (size_t)B * Hin * Win * 3;
+        if (nb > ctx->u8_bytes) { CHK(dev_realloc(ctx, &ctx->d_u8, nb)); ctx->u8_bytes = nb; }
+        HIPCHK(ctx, hipMemcpyAsync(ctx->d_u8, image_u8, nb, hipMemcpyHostToDevice, ctx->stream));
+        preprocess_u8_launch(ctx->d_u8, B, Hin, Win, H, W, ctx->d_image, ctx->stream);
+        CHK(copy_in(ctx, ctx->d_hs, hand_side, (size_t)B * 2, false));
+        d_img = ctx->d_image; d_hs = ctx->d_hs;
+    } else if (!dev) {
         CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
         CHK(copy_in(ctx, ctx->d_hs, hand_side, (size_t)B * 2, false));
         d_img = ctx->d_image; d_hs = ctx->d_hs;
@@ -749,6 +763,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     if (ctx->d_seed) hipFree(ctx->d_seed);
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
+    if (ctx->d_u8) hipFree(ctx->d_u8);
     for (auto& kv : ctx->naive_w) hipFree(kv.second);
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -919,6 +934,25 @@ int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, 
                            keypoints_scoremap, keypoint_coord3d, hand_mask, true);
 }
 
+int hp3d_infer_full_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* image_u8, int H, int W,
+                       const float* hand_side, float* hand_scoremap, float* image_crop, float* scale_crop,
+                       float* center, float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask) {
+    return infer_full_impl(ctx, B, H, W, nullptr, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                           keypoints_scoremap, keypoint_coord3d, hand_mask, false, image_u8, Hin, Win);
+}
+
+int hp3d_preprocess_u8(hp3d_ctx* ctx, const uint8_t* image_u8, int B, int Hin, int Win, int H, int W, float* out) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!image_u8 || !out || B < 1 || Hin < 2 || Win < 2 || H < 1 || W < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    unsigned char* d_in = S.upload(image_u8, (size_t)B * Hin * Win * 3); NN(ctx, d_in);
+    float* d_o = S.alloc<float>((size_t)B * H * W * 3); NN(ctx, d_o);
+    preprocess_u8_launch(d_in, B, Hin, Win, H, W, d_o, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, d_o, sizeof(float) * (size_t)B * H * W * 3, hipMemcpyDeviceToHost, ctx->stream));
+    return finish_op(ctx);
+}
+
 int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
                   float* image_crop, float* scale_crop, float* center) {
     if (!ctx) return HP3D_ERR_ARG;
@@ -985,7 +1019,7 @@ int hp3d_poseprior(hp3d_ctx* ctx, int B, int variant, const float* scoremap256, 
                    float* coord_xyz_rel_normed, float* coord3d, float* rot_mat) {
     if (!ctx) return HP3D_ERR_ARG;
     if (!scoremap256 || !hand_side || B < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
-    if (variant < 0 || variant > 2) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "Unknown variant.");
+    if (variant < 0 || variant > 3) HP3D_FAIL(ctx, HP3D_ERR_ARG, "Unknown variant.");
     CHK(need_nets(ctx, variant == HP3D_VARIANT_PROPOSED ? (NET_PRIOR | NET_VP)
                        : variant == HP3D_VARIANT_BOTTLENECK ? (NET_PRIOR | NET_BOTTLENECK) : NET_PRIOR));
     HIPCHK(ctx, hipSetDevice(ctx->device));

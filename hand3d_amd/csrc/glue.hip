@@ -145,6 +145,31 @@ void resize_bilinear_kernel(const float* x, int B, int H, int W, int C, int in_c
     }
 }
 
+// Input pre-processing on device: uint8 image -> `x/255 - 0.5` (data/BinaryDbReader.py:182,
+// run.py:59) -> tf.image.resize_images to the network size (eval_full.py:50, eval2d.py:53), fused:
+// 4x less H2D traffic, no float image round trip.  Same float32 op order as the oracle (bit-exact).
+HP3D_KERNEL(256)
+void preprocess_u8_kernel(const unsigned char* img, int B, int H, int W, int oh, int ow, float* out) {
+    const float hscale = (float)H / (float)oh, wscale = (float)W / (float)ow;
+    const long total = (long)B * oh * ow * 3;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % 3);
+        long r = i / 3;
+        const int ox = (int)(r % ow); r /= ow;
+        const int oy = (int)(r % oh);
+        const int b = (int)(r / oh);
+        int y0, y1, x0, x1; float ty, tx;
+        resize_coord(oy, hscale, H, y0, y1, ty);
+        resize_coord(ox, wscale, W, x0, x1, tx);
+        const unsigned char* ib = img + (size_t)b * H * W * 3 + c;
+        const float tl = (float)ib[((size_t)y0 * W + x0) * 3] / 255.0f - 0.5f, tr = (float)ib[((size_t)y0 * W + x1) * 3] / 255.0f - 0.5f;
+        const float bl = (float)ib[((size_t)y1 * W + x0) * 3] / 255.0f - 0.5f, br = (float)ib[((size_t)y1 * W + x1) * 3] / 255.0f - 0.5f;
+        const float top = tl + (tr - tl) * tx;
+        const float bot = bl + (br - bl) * tx;
+        out[i] = (oh == H && ow == W) ? tl : top + (bot - top) * ty;
+    }
+}
+
 // crop_image_from_xy -> tf.image.crop_and_resize (utils/general.py:163-196, App. B.4)
 HP3D_KERNEL(256)
 void crop_and_resize_kernel(const float* img, int B, int H, int W, int C, const float* center, const float* scale,
@@ -500,6 +525,38 @@ void lift_epilogue_kernel(const float* u, const float* can, const float* hand_si
     }
 }
 
+// bone_rel_trafo_inv (utils/relative_trafo.py:243-295; PosePriorNetwork variants 'local*',
+// nets/PosePriorNetwork.py:70-75).  One thread per image walks the 5 finger chains root -> tip.
+// The chain transform T (global -> bone frame) is rigid, T = [R | t], so the reference's
+//   T_new = Trans_z(-len) * RotX(-ax) * RotY(-ay) * T_parent ;  x = matrix_inverse(T_new) * (0,0,0,1)^T
+// is evaluated as R_new = M R, t_new = M t + (0,0,-len), x = -R_new^T t_new  (M = RotX(-ax) RotY(-ay)).
+HP3D_KERNEL(64)
+void bone_rel_inv_kernel(const float* rel, int B, float* xyz) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int chains[6][4] = {{0, -1, -1, -1}, {4, 3, 2, 1}, {8, 7, 6, 5}, {12, 11, 10, 9}, {16, 15, 14, 13}, {20, 19, 18, 17}};
+    for (int ci = 0; ci < 6; ++ci) {
+        float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, tv[3] = {0, 0, 0};
+        for (int k = 0; k < 4; ++k) {
+            const int bone = chains[ci][k];
+            if (bone < 0) break;
+            const float len = rel[b * 63 + bone * 3], ax = -rel[b * 63 + bone * 3 + 1], ay = -rel[b * 63 + bone * 3 + 2];
+            const float cx = cosf(ax), sx = sinf(ax), cy = cosf(ay), sy = sinf(ay);
+            // M = RotX(ax) * RotY(ay), RotX = [1 0 0; 0 c -s; 0 s c], RotY = [c 0 s; 0 1 0; -s 0 c]
+            const float M[9] = {cy, 0.f, sy, sx * sy, cx, -sx * cy, -cx * sy, sx, cx * cy};
+            float Rn[9], tn[3];
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) Rn[i * 3 + j] = (M[i * 3] * R[j] + M[i * 3 + 1] * R[3 + j]) + M[i * 3 + 2] * R[6 + j];
+                tn[i] = (M[i * 3] * tv[0] + M[i * 3 + 1] * tv[1]) + M[i * 3 + 2] * tv[2];
+            }
+            tn[2] -= len;
+            for (int i = 0; i < 9; ++i) R[i] = Rn[i];
+            for (int i = 0; i < 3; ++i) tv[i] = tn[i];
+            for (int j = 0; j < 3; ++j) xyz[b * 63 + bone * 3 + j] = -((R[j] * tv[0] + R[3 + j] * tv[1]) + R[6 + j] * tv[2]);
+        }
+    }
+}
+
 // detect_keypoints (utils/general.py:331-344): first arg-max per channel; one workgroup per (b,c)
 __device__ __forceinline__ unsigned ord_f32(float f) {
     const unsigned u = __float_as_uint(f);
@@ -563,6 +620,9 @@ void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_c
     HP3D_LAUNCH(resize_bilinear_kernel, dim3(grid_for((long)B * oh * ow * C)), dim3(256), 0, s, x, B, H, W, C, in_cs,
                 oh, ow, out);
 }
+void preprocess_u8_launch(const unsigned char* img, int B, int H, int W, int oh, int ow, float* out, hipStream_t s) {
+    HP3D_LAUNCH(preprocess_u8_kernel, dim3(grid_for((long)B * oh * ow * 3)), dim3(256), 0, s, img, B, H, W, oh, ow, out);
+}
 void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const float* center, const float* scale,
                             int crop, float* out, hipStream_t s) {
     HP3D_LAUNCH(crop_and_resize_kernel, dim3(grid_for((long)B * crop * crop)), dim3(256), 0, s, img, B, H, W, C,
@@ -617,6 +677,9 @@ void lift_epilogue_launch(const float* u, const float* coord_can, const float* h
                           float* coord_rel, int do_flip_rot, hipStream_t s) {
     HP3D_LAUNCH(lift_epilogue_kernel, dim3((B + 63) / 64), dim3(64), 0, s, u, coord_can, hand_side, B, rot, coord_rel,
                 do_flip_rot);
+}
+void bone_rel_inv_launch(const float* rel, int B, float* xyz, hipStream_t s) {
+    HP3D_LAUNCH(bone_rel_inv_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rel, B, xyz);
 }
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s) {
     HP3D_LAUNCH(argmax2d_kernel, dim3(C, B), dim3(256), 0, s, x, H, W, C, cs, out_rc);

@@ -85,6 +85,7 @@ void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, floa
 void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int out_cs, hipStream_t s);
 void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs,
                             int oh, int ow, float* out, hipStream_t s);
+void preprocess_u8_launch(const unsigned char* img, int B, int H, int W, int oh, int ow, float* out, hipStream_t s);
 void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const float* center,
                             const float* scale, int crop, float* out, hipStream_t s);
 
@@ -110,6 +111,7 @@ void concat_handside_launch(const float* feat, int B, int F, const float* hand_s
 // u = (ux,uy,uz) [B,3], coord_can [B,63], hand_side [B,2] -> rot [B,9], coord_rel [B,63]
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B,
                           float* rot, float* coord_rel, int do_flip_rot, hipStream_t s);
+void bone_rel_inv_launch(const float* rel, int B, float* xyz, hipStream_t s);   // [B,21,3] local -> xyz
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s);
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s);
 void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s);

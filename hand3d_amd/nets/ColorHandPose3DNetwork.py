@@ -71,6 +71,14 @@ class ColorHandPose3DNetwork(object):
         o = self.engine.infer_full(image, hand_side)
         return o['scoremap'], o['crop'], o['scale'], o['center'], o['kpmap'], o['coord3d']
 
+    def inference_from_uint8(self, image_u8, hand_side, evaluation, net_size=(240, 320)):
+        """ Not in the reference class: the scripts' pre-processing (`x/255 - 0.5`, run.py:59 /
+            data/BinaryDbReader.py:182, then resize to 240x320, eval_full.py:50) fused in front of
+            inference() on the device.  Same 6-tuple as inference(). """
+        self._check_eval(evaluation)
+        o = self.engine.infer_full_u8(image_u8, hand_side, net_size[0], net_size[1])
+        return o['scoremap'], o['crop'], o['scale'], o['center'], o['kpmap'], o['coord3d']
+
     def inference2d(self, image):
         """ Only 2D part of the pipeline: HandSegNet + PoseNet (reference :101-129).
             Returns keypoints_scoremap, image_crop, scale_crop, center -- note the order. """

@@ -1,7 +1,7 @@
 """PosePriorNetwork -- nets/PosePriorNetwork.py:30-95 of the reference on the MI355X engine.
 
-Variants 'direct', 'bottleneck', 'proposed' run on the engine; 'local' / 'local_w_xyz_loss' need
-bone_rel_trafo_inv (utils/relative_trafo.py) and raise NotImplementedError.
+All five variants run on the engine: 'direct', 'bottleneck', 'proposed', and 'local' /
+'local_w_xyz_loss' (PosePrior net + bone_rel_trafo_inv, utils/relative_trafo.py:243-295).
 """
 from __future__ import print_function, unicode_literals
 
@@ -31,7 +31,5 @@ class PosePriorNetwork(object):
             Returns (coord_xyz_rel_normed, coord3d, R); R is None for direct/bottleneck. """
         if not bool(evaluation):
             raise NotImplementedError("inference engine: evaluation=False (dropout active) is a training path")
-        if self.variant in ('local', 'local_w_xyz_loss'):
-            raise NotImplementedError("variant %r needs bone_rel_trafo_inv (SURVEY.md 8f N3)" % self.variant)
-        assert self.variant in ('direct', 'bottleneck', 'proposed'), "Unknown variant."
+        assert self.variant in ('direct', 'bottleneck', 'proposed', 'local', 'local_w_xyz_loss'), "Unknown variant."
         return self.engine.poseprior(self.variant, scoremap, hand_side)

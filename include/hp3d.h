@@ -36,12 +36,13 @@ typedef enum {
     HP3D_ERR_ARG = -1,        /* bad argument / shape (the reference's bare asserts)            */
     HP3D_ERR_HIP = -2,        /* a HIP runtime call failed                                      */
     HP3D_ERR_WEIGHTS = -3,    /* missing / mis-shaped variable at finalize, or not finalized    */
-    HP3D_ERR_UNSUPPORTED = -4,/* e.g. variant 'local' (SURVEY.md 8f N3), evaluation=False       */
+    HP3D_ERR_UNSUPPORTED = -4,/* e.g. evaluation=False / train=True, unsupported geometry          */
     HP3D_ERR_NOMEM = -5
 } hp3d_status;
 
 /* PosePriorNetwork variants -- nets/PosePriorNetwork.py:59-95 */
-enum { HP3D_VARIANT_DIRECT = 0, HP3D_VARIANT_BOTTLENECK = 1, HP3D_VARIANT_PROPOSED = 2 };
+enum { HP3D_VARIANT_DIRECT = 0, HP3D_VARIANT_BOTTLENECK = 1, HP3D_VARIANT_PROPOSED = 2,
+       HP3D_VARIANT_LOCAL = 3 /* 'local' and 'local_w_xyz_loss': + bone_rel_trafo_inv, utils/relative_trafo.py:243-295 */ };
 /* activation fused behind a conv / fc -- utils/general.py:55-59,132-136 */
 enum { HP3D_ACT_NONE = 0, HP3D_ACT_LEAKY = 1 };
 
@@ -89,7 +90,7 @@ int hp3d_nets_mask(hp3d_ctx* ctx);   /* bit0 HandSegNet, bit1 PoseNet2D, bit2 Po
  * hp3d_posenet2d    replaces .inference_pose2d (:170-219): the 3 scoremaps [B,h/8,w/8,21].
  * hp3d_poseprior    replaces PosePriorNetwork(variant).inference (nets/PosePriorNetwork.py:59-95):
  *   scoremap256 [B,256,256,21] -> coord_xyz_rel_normed [B,21,3], coord3d [B,21,3], R [B,3,3]
- *   (R untouched for direct/bottleneck, where the reference returns None).
+ *   (R untouched for direct/bottleneck/local, where the reference returns None).
  * hp3d_pose3d       replaces ._inference_pose3d (:221-247) on a [B,32,32,21] scoremap.
  * hand_mask (extra, may be NULL): the internal objectmap [B,H,W] of single_obj_scoremap
  *   (utils/general.py:233-268), exposed so tests can assert mask equality first.            */
@@ -99,6 +100,13 @@ int hp3d_infer_full(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
 int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                         float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
                         float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask);
+/* SURVEY.md 8f N2 -- the step immediately before the hot path, on device: uint8 frames
+ * [B,Hin,Win,3] -> x/255-0.5 (data/BinaryDbReader.py:182, run.py:59) -> tf.image.resize_images to H x W
+ * (eval_full.py:50, eval2d.py:53; equal sizes = identity) -> hp3d_infer_full.  4x less H2D traffic.      */
+int hp3d_infer_full_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* image_u8, int H, int W,
+                       const float* hand_side, float* hand_scoremap, float* image_crop, float* scale_crop,
+                       float* center, float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask);
+int hp3d_preprocess_u8(hp3d_ctx* ctx, const uint8_t* image_u8, int B, int Hin, int Win, int H, int W, float* out);
 int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image,
                   float* keypoints_scoremap, float* image_crop, float* scale_crop, float* center);
 int hp3d_handsegnet(hp3d_ctx* ctx, int B, int H, int W, const float* image,

@@ -148,6 +148,13 @@ def scale_from_crop_size(crop_size_best, crop_size=256):
     return np.minimum(np.maximum(sc, F32(0.25)), F32(5.0)).astype(F32)
 
 
+def preprocess_u8(image_u8, out_h, out_w):
+    """The scripts' input pre-processing: `image/255.0 - 0.5` in float32 (data/BinaryDbReader.py:182,
+    run.py:59) then tf.image.resize_images(image, (240, 320)) (eval_full.py:50, eval2d.py:53)."""
+    x = (np.asarray(image_u8).astype(F32) / F32(255.0) - F32(0.5)).astype(F32)
+    return T.resize_bilinear_legacy(x, out_h, out_w)
+
+
 def detect_keypoints(scoremaps):
     """utils/general.py:331-344.  [H,W,C] -> float64 [C,2] (v=row, u=col)."""
     if len(scoremaps.shape) == 4:

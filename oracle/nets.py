@@ -223,5 +223,7 @@ def poseprior_network(weights, variant, scoremap256, hand_side, evaluation=True,
         rel, can, R = pose3d(weights, pooled, hand_side, acc, taps)
         return rel, can, R
     if variant in ('local', 'local_w_xyz_loss'):
-        raise NotImplementedError("bone_rel_trafo_inv variants are SURVEY.md 8f row N3 (next)")
+        from .relative_trafo import bone_rel_trafo_inv
+        loc = poseprior_can(weights, pooled, hand_side, acc, taps)
+        return bone_rel_trafo_inv(loc), loc, None
     assert 0, "Unknown variant."

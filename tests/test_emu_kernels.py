@@ -104,3 +104,29 @@ def test_full_pipeline_on_interpreter(emu_engine, synth_weights):
     ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
     for a, b in zip(out, ref):
         assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
+
+
+def test_local_variant_bone_rel_trafo_inv(emu_engine, synth_weights):
+    """PosePriorNetwork('local'): PosePrior net + bone_rel_trafo_inv (utils/relative_trafo.py:243-295)."""
+    from hand3d_amd import PosePriorNetwork
+    from oracle import relative_trafo as RT
+    rng = np.random.default_rng(12)
+    xyz = rng.standard_normal((3, 21, 3)).astype(np.float32)
+    assert np.abs(RT.bone_rel_trafo_inv(RT.bone_rel_trafo(xyz)) - xyz).max() < 1e-5     # round trip pins the restatement
+    sm = np.maximum(rng.standard_normal((2, 256, 256, 21)).astype(np.float32), 0) * 0.2
+    hs = synth.hand_sides(2)
+    net = PosePriorNetwork('local', engine=emu_engine)
+    net.init_from_dict({k: v for k, v in synth_weights.items() if k.startswith('PosePrior')})
+    rel, c3d, R = net.inference(sm, hs, True)
+    rrel, rc3d, rR = N.poseprior_network(synth_weights, 'local', sm, hs, acc=np.float64)
+    assert R is None and rR is None
+    assert np.abs(c3d - rc3d).max() < 1e-5 and np.abs(rel - rrel).max() < 1e-5
+
+
+def test_preprocess_u8_on_interpreter(emu_engine):
+    """uint8 -> x/255-0.5 -> legacy bilinear resize, bit-exact vs the oracle."""
+    rng = np.random.default_rng(21)
+    u8 = rng.integers(0, 256, size=(2, 48, 64, 3), dtype=np.uint8)
+    assert np.array_equal(emu_engine.preprocess_u8(u8, 24, 32), G.preprocess_u8(u8, 24, 32))
+    assert np.array_equal(emu_engine.preprocess_u8(u8, 48, 64), u8.astype(np.float32) / np.float32(255) - np.float32(0.5))
+    assert np.array_equal(emu_engine.preprocess_u8(u8, 30, 50), G.preprocess_u8(u8, 30, 50))

@@ -252,8 +252,11 @@ def test_pose3d_and_poseprior_variants(gpu_engine, synth_weights):
     rel, _, R = bn.inference(sm256, hs, True)
     rrel, _, _ = N.poseprior_network(wb, 'bottleneck', sm256, hs, acc=np.float64)
     assert R is None and np.abs(rel - rrel).max() < TOL_KP3D
-    with pytest.raises(NotImplementedError):
-        PosePriorNetwork('local', engine=gpu_engine).inference(sm256, hs, True)
+    lo = PosePriorNetwork('local', engine=gpu_engine)          # PosePrior net + bone_rel_trafo_inv
+    lo.init_from_dict(wprior)
+    rel, c3d, R = lo.inference(sm256, hs, True)
+    rrel, rc3d, _ = N.poseprior_network(synth_weights, 'local_w_xyz_loss', sm256, hs, acc=np.float64)
+    assert R is None and np.abs(c3d - rc3d).max() < TOL_KP3D and np.abs(rel - rrel).max() < TOL_KP3D
     # restore the standard weight set for later tests
     gpu_engine.load_weight_dict(synth_weights)
     gpu_engine.finalize_weights()
@@ -326,6 +329,23 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
     assert np.abs(o1[0] - ref[0]).max() < TOL_HEATMAP
     assert np.array_equal(o1[3], ref[3]) and np.array_equal(o1[2], ref[2])
     assert np.abs(o1[4] - ref[4]).max() < TOL_HEATMAP and np.abs(o1[5] - ref[5]).max() < TOL_KP3D
+
+
+def test_uint8_frontend_matches_float_path(net, synth_weights):
+    """320x320 uint8 RHD-sized frames -> normalise + resize to 240x320 on device ->
+    inference(); identical to feeding the oracle-preprocessed float image (eval_full.py:50 order)."""
+    rng = np.random.default_rng(31)
+    base = (synth.make_batch(400, 2, 320, 320) + 0.5) * 255.0
+    u8 = np.clip(np.rint(base + rng.normal(0, 2, base.shape)), 0, 255).astype(np.uint8)
+    hs = synth.hand_sides(2)
+    pre = G.preprocess_u8(u8, 240, 320)
+    assert np.array_equal(net.engine.preprocess_u8(u8, 240, 320), pre)
+    a = net.inference_from_uint8(u8, hs, True, net_size=(240, 320))
+    b = net.inference(pre, hs, True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    ref = N.inference(synth_weights, pre, hs, True, acc=np.float64)
+    assert np.array_equal(a[3], ref[3]) and np.abs(a[5] - ref[5]).max() < TOL_KP3D
 
 
 def test_golden_fixtures_gpu(net, synth_weights):

@@ -71,9 +71,6 @@ def test_error_behaviour(emu_engine, synth_weights):
     with pytest.raises(AssertionError, match="Unknown variant."):
         PosePriorNetwork('bogus', engine=emu_engine).inference(np.zeros((1, 256, 256, 21), np.float32),
                                                                 np.array([[1., 0.]], np.float32), True)
-    with pytest.raises(NotImplementedError):
-        PosePriorNetwork('local', engine=emu_engine).inference(np.zeros((1, 256, 256, 21), np.float32),
-                                                               np.array([[1., 0.]], np.float32), True)
 
 
 def test_incomplete_network_is_rejected(emu_engine, synth_weights):

@@ -1,0 +1,69 @@
+#!/usr/bin/env python
+"""eval2d.py / eval2d_gt_cropped.py of the reference on the engine.
+  default        : HandSegNet + PoseNet on RHD-e scaled to 240x320 (eval2d.py:44-112)
+  --gt-cropped   : PoseNet only on GT hand crops (eval2d_gt_cropped.py:37-101)"""
+import os
+import tempfile
+
+import numpy as np
+
+from common import parser, synthetic_weight_files
+
+if __name__ == '__main__':
+    ap = parser(__doc__)
+    ap.add_argument('--db', default=None)
+    ap.add_argument('--gt-cropped', action='store_true')
+    a = ap.parse_args()
+    from hand3d_amd.data import BinaryDbReader, binary_format as fmt
+    from hand3d_amd.nets.ColorHandPose3DNetwork import ColorHandPose3DNetwork
+    from hand3d_amd.utils.general import EvalUtil, detect_keypoints, trafo_coords
+
+    net = ColorHandPose3DNetwork(device=a.device)
+    if a.synthetic:
+        tmp = tempfile.mkdtemp()
+        files = synthetic_weight_files(tmp)
+        rng = np.random.default_rng(0)
+        a.db = os.path.join(tmp, 'rhd_evaluation.bin')
+        with open(a.db, 'wb') as f:
+            for _ in range(a.limit or 4):
+                mask = np.zeros((320, 320), np.uint8)
+                mask[100:200, 80:220] = 5
+                f.write(fmt.pack_rhd_record(rng.integers(0, 256, (320, 320, 3), dtype=np.uint8), mask, rng.normal(0, .05, (42, 3)),
+                                            rng.uniform(90, 210, (42, 2)), np.ones(42), np.eye(3)))
+        files_pose = files
+    else:
+        files = ['%s/handsegnet-rhd.pickle' % a.weights_dir, '%s/posenet-rhd-stb.pickle' % a.weights_dir]
+        files_pose = files[1:]
+    util = EvalUtil()
+    if a.gt_cropped:
+        net.init(None, weight_files=files_pose, exclude_var_list=['PosePrior', 'ViewpointNet', 'HandSegNet'])
+        dataset = BinaryDbReader(mode='evaluation', shuffle=False, hand_crop=True, use_wrist_coord=False,
+                                 path_to_db=a.db, engine=net.engine)                                 # eval2d_gt_cropped.py:37
+        for i, data in enumerate(dataset.get()):
+            if a.limit and i >= a.limit:
+                break
+            scoremap = net.inference_pose2d(data['image_crop'])[-1]                                  # :45-46
+            scoremap = net.engine.resize_bilinear(scoremap, 256, 256)                                 # :50
+            kp_uv21_gt = np.squeeze(data['keypoint_uv21'])
+            coord_hw_pred_crop = detect_keypoints(np.squeeze(scoremap))
+            coord_uv_pred_crop = np.stack([coord_hw_pred_crop[:, 1], coord_hw_pred_crop[:, 0]], 1)
+            cs = np.squeeze(data['crop_scale'])
+            util.feed(kp_uv21_gt / cs, np.squeeze(data['keypoint_vis21']), coord_uv_pred_crop / cs)   # :79-82
+    else:
+        net.init(None, weight_files=files, exclude_var_list=['PosePrior', 'ViewpointNet'])            # eval2d.py:78-79
+        dataset = BinaryDbReader(mode='evaluation', shuffle=False, use_wrist_coord=True, scale_to_size=True,
+                                 path_to_db=a.db, engine=net.engine)                                 # eval2d.py:44
+        for i, data in enumerate(dataset.get()):
+            if a.limit and i >= a.limit:
+                break
+            keypoints_scoremap, image_crop, scale_crop, center = net.inference2d(data['image'])      # eval2d.py:58
+            coord_hw_crop = detect_keypoints(np.squeeze(keypoints_scoremap))
+            coord_hw = trafo_coords(coord_hw_crop, center, scale_crop, 256)
+            coord_uv = np.stack([coord_hw[:, 1], coord_hw[:, 0]], 1)                                  # eval2d.py:93-99
+            util.feed(np.squeeze(data['keypoint_uv21']) / np.squeeze(scale_crop), np.squeeze(data['keypoint_vis21']),
+                      coord_uv / np.squeeze(scale_crop))
+    mean, median, auc, _, _ = util.get_measures(0.0, 30.0, 20)                                        # eval2d.py:112
+    print('Evaluation results:')
+    print('Average mean EPE: %.3f pixels' % mean)
+    print('Average median EPE: %.3f pixels' % median)
+    print('Area under curve: %.3f' % auc)

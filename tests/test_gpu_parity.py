@@ -331,6 +331,20 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
     assert np.abs(o1[4] - ref[4]).max() < TOL_HEATMAP and np.abs(o1[5] - ref[5]).max() < TOL_KP3D
 
 
+def test_full_pipeline_480x640_config_c5_shape(net, synth_weights):
+    """BASELINE config 5 input shape (640x480 RGB stream), float32 path: 64 growth passes allowed, bigger mask."""
+    img = synth.make_batch(1000, 3, 480, 640)
+    hs = synth.hand_sides(3)
+    o = net.engine.infer_full(img, hs, want_mask=True)
+    taps = {}
+    ref = N.inference(synth_weights, img[:1], hs[:1], True, acc=np.float64, taps=taps)
+    assert np.array_equal(o['mask'][0], taps['hand_mask'][0, :, :, 0])
+    assert np.array_equal(o['center'][:1], ref[3]) and np.array_equal(o['scale'][:1], ref[2])
+    assert np.abs(o['scoremap'][:1] - ref[0]).max() < TOL_HEATMAP and np.abs(o['kpmap'][:1] - ref[4]).max() < TOL_HEATMAP
+    assert np.abs(o['coord3d'][:1] - ref[5]).max() < TOL_KP3D
+    assert np.isfinite(o['coord3d']).all() and np.isfinite(o['kpmap']).all()
+
+
 def test_uint8_frontend_matches_float_path(net, synth_weights):
     """320x320 uint8 RHD-sized frames -> normalise + resize to 240x320 on device ->
     inference(); identical to feeding the oracle-preprocessed float image (eval_full.py:50 order)."""

@@ -219,27 +219,43 @@ void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    bool patch_ready = false;
+    if constexpr (KS == 1 && STRIDE == 1) {
     if (p.im2col) {
+        patch_ready = true;
         // conv1_1 (Cin = 3, utils/general.py:36-53 at nets/ColorHandPose3DNetwork.py:144,183): the A tile is
         // built straight from the [B,H,W,3] image as K = (r*3+s)*3+c (27 real + 5 zero) -- no im2col
         // buffer in HBM.  KS == 1 here, so the "patch" is the tile itself.
+        // The raw (PH+2) x (PW+2) x 3 image window is staged once in LDS (coalesced loads, one bounds check
+        // per element, zero fill = SAME padding); the 32-wide rows are then gathered from LDS.  The
+        // third weight-ring slot is free here (one K step only) and serves as the staging area.
         const float* img = p.in + (size_t)b * p.H * p.W * 3;
+        float* raw = wbuf + 2 * C::WBUF_FLOATS;
+        constexpr int RW = PW + 2, RH = PH + 2;
+        static_assert(RH * RW * 3 <= C::WBUF_FLOATS, "raw image window must fit one weight slot");
+        for (int i = tid; i < RH * RW * 3; i += NTHR) {
+            const int c = i % 3, q = i / 3;
+            const int ry = q / RW, rx = q - ry * RW;
+            const int iy = gy0 + ry - 1, ix = gx0 + rx - 1;
+            float v = 0.f;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = img[(iy * p.W + ix) * 3 + c];
+            raw[i] = v;
+        }
+        __syncthreads();
         for (int idx = tid; idx < PH * PW * 8; idx += NTHR) {
             const int pix = idx >> 3, c4 = idx & 7;
             const int py = pix / PW, px = pix - py * PW;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int k = c4 * 4 + e;
-                if (k < 27) {
-                    const int tp = k / 3, c = k - tp * 3;
-                    const int iy = gy0 + py + tp / 3 - 1, ix = gx0 + px + tp % 3 - 1;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v[e] = img[(iy * p.W + ix) * 3 + c];
-                }
+                const int k = c4 * 4 + e;                 // k = (r*3+s)*3 + c
+                if (k < 27) v[e] = raw[((py + k / 9) * RW + px + (k / 3) % 3) * 3 + k % 3];
             }
             *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
         }
-    } else {
+    }
+    }
+    if (!patch_ready) {
         patch_fetch(0);
         patch_commit();
     }
@@ -378,8 +394,10 @@ int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cin, int Cout, int poo
     while (blocks < 256 && bn > 32) { bn >>= 1; blocks <<= 1; }       // narrower cout tiles
     int ksplit = 1;
     const int nch = Cin / 32;
-    if (!pool && blocks < 256 && nch > 1) {                            // still under-filled: split K
-        ksplit = (int)((256 + blocks - 1) / blocks);
+    // narrow (bn = 32) workgroups are 2 waves / 26 KB of LDS: ~6 fit on a CU, so aim higher before giving up
+    const long want = (bn == 32 && blocks < 768) ? 768 : 256;
+    if (!pool && blocks < want && nch > 1) {                           // still under-filled: split K
+        ksplit = (int)((want + blocks - 1) / blocks);
         if (ksplit > nch) ksplit = nch;
         if (ksplit > 16) ksplit = 16;
     }

@@ -123,16 +123,17 @@ __device__ __forceinline__ void resize_coord(int o, float scale, int in_n, int& 
     t = src - (float)lo;
 }
 
+template <typename IDX>      // IDX = unsigned when the element count fits 32 bits (3x fewer index instructions)
 HP3D_KERNEL(256)
 void resize_bilinear_kernel(const float* x, int B, int H, int W, int C, int in_cs, int oh, int ow, float* out) {
     const float hscale = (float)H / (float)oh, wscale = (float)W / (float)ow;
-    const long total = (long)B * oh * ow * C;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long r = i / C;
-        const int ox = (int)(r % ow); r /= ow;
-        const int oy = (int)(r % oh);
-        const int b = (int)(r / oh);
+    const IDX total = (IDX)B * oh * ow * C;
+    for (IDX i = (IDX)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (IDX)gridDim.x * blockDim.x) {
+        const int c = (int)(i % (IDX)C);
+        IDX r = i / (IDX)C;
+        const int ox = (int)(r % (IDX)ow); r /= (IDX)ow;
+        const int oy = (int)(r % (IDX)oh);
+        const int b = (int)(r / (IDX)oh);
         int y0, y1, x0, x1; float ty, tx;
         resize_coord(oy, hscale, H, y0, y1, ty);
         resize_coord(ox, wscale, W, x0, x1, tx);
@@ -334,9 +335,20 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
     for (int w = tid; w < NWORD; w += nthr) {
         const int y = w / WW, wx = w - y * WW;
         unsigned bits = 0;
-        for (int k = 0; k < 32; ++k) {
-            const int x = wx * 32 + k;
-            if (x < W && d[(size_t)y * W + x]) bits |= (1u << k);
+        const unsigned char* row = d + (size_t)y * W + wx * 32;
+        if (wx * 32 + 32 <= W && ((W & 7) == 0)) {          // 4 aligned 8-byte loads instead of 32 byte loads
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned long long v = *(const unsigned long long*)(row + q * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if ((v >> (8 * k)) & 0xffull) bits |= (1u << (q * 8 + k));
+            }
+        } else {
+            for (int k = 0; k < 32; ++k) {
+                const int x = wx * 32 + k;
+                if (x < W && row[k]) bits |= (1u << k);
+            }
         }
         detb[w] = bits;
         obj[w] = (y == sy && wx == (sx >> 5)) ? (1u << (sx & 31)) : 0u;
@@ -617,8 +629,14 @@ void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int
 }
 void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs, int oh, int ow, float* out,
                             hipStream_t s) {
-    HP3D_LAUNCH(resize_bilinear_kernel, dim3(grid_for((long)B * oh * ow * C)), dim3(256), 0, s, x, B, H, W, C, in_cs,
-                oh, ow, out);
+    const long total = (long)B * oh * ow * C;
+    if (total < (1L << 31)) {
+        auto k32 = resize_bilinear_kernel<unsigned>;
+        HP3D_LAUNCH(k32, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, x, B, H, W, C, in_cs, oh, ow, out);
+    } else {
+        auto k64 = resize_bilinear_kernel<unsigned long>;
+        HP3D_LAUNCH(k64, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, x, B, H, W, C, in_cs, oh, ow, out);
+    }
 }
 void preprocess_u8_launch(const unsigned char* img, int B, int H, int W, int oh, int ow, float* out, hipStream_t s) {
     HP3D_LAUNCH(preprocess_u8_kernel, dim3(grid_for((long)B * oh * ow * 3)), dim3(256), 0, s, img, B, H, W, oh, ow, out);

@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: bf16/f16 MFMA, dense
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -39,6 +40,8 @@ def parse():
     ap.add_argument('--workload', default='full', choices=['full', 'posenet'])
     ap.add_argument('--cpu-images', type=int, default=3, help='oracle images timed for cpu_baseline (0 = skip)')
     ap.add_argument('--layers', action='store_true', help='print the per-layer table to stderr')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'],
+                    help="f32 = exact f32 MFMA (headline); f16 = half-precision trunks, BASELINE config 5 (looser parity)")
     ap.add_argument('--streams', type=int, default=1, help='engine contexts (HIP streams) per GPU; the per-GPU batch is split across them')
     return ap.parse_args()
 
@@ -87,13 +90,13 @@ def main():
     eng = Engine(local)     # raises if libhp3d.so is missing: no fallback
     B, H, W = a.batch, a.height, a.width
     weights = synth.make_weights() if rank == 0 else None
-    ShardedPipeline(eng, rank, world).sync_weights(weights, device=dev)
+    ShardedPipeline(eng, rank, world).sync_weights(weights, device=dev, dtype=a.dtype)
     # extra contexts on the same GPU: independent HIP streams whose kernels overlap (one context's tail /
     # prologue / launch gaps are filled by the other's bulk); they get the weights by a device-to-device blob copy
     engines = [eng]
     for _ in range(a.streams - 1):
         e2 = Engine(local)
-        blob = torch.empty(eng.blob_bytes() // 4, dtype=torch.float32, device=dev)
+        blob = torch.empty((eng.blob_bytes() + 3) // 4, dtype=torch.float32, device=dev)
         eng.blob_export(blob.data_ptr())
         e2.blob_import(blob.data_ptr(), eng.nets_mask())
         del blob
@@ -160,13 +163,14 @@ def main():
         # scripts/summarize_prof.py -> profiles/conv_mfma_traffic.json); counters cannot be read in-process.
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'conv_mfma_traffic.json')
-        if dom == 'conv_mfma' and a.workload == 'full' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
+        if dom == 'conv_mfma' and a.workload == 'full' and a.dtype == 'f32' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
             try:
                 traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+        peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_F16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per launch (PMC, profiles/conv_mfma_traffic.json)",
                 "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
                 "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
@@ -191,7 +195,7 @@ def main():
                       if a.workload == 'full' else "images/sec PoseNet2D only (256x256 crops)",
             "value": round(n_img / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded images, seeded fan-in-scaled weights)",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded images, seeded fan-in-scaled weights)",
             "config": {"workload": ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step"
                                     % (H, W, B)) if a.workload == 'full' else
                                    ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B),

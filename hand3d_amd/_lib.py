@@ -148,7 +148,9 @@ class Engine(object):
             self.set_weight(k, weight_dict[k])
 
     def finalize_weights(self, dtype=0):
-        self._chk(self.lib.hp3d_finalize_weights(self.h, dtype))
+        """dtype 0 = float32; 1 (or 'f16') = half-precision HandSegNet / PoseNet2D trunks (BASELINE config 5)."""
+        dtype = {'f32': 0, 'f16': 1}.get(dtype, dtype)
+        self._chk(self.lib.hp3d_finalize_weights(self.h, int(dtype)))
 
     def nets_mask(self):
         return self.lib.hp3d_nets_mask(self.h)

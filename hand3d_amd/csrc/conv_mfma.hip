@@ -46,7 +46,13 @@ struct ConvCfg {
     static_assert((CK * BN / 4) % NTHR == 0, "weight copy must divide evenly");
 };
 
-template <int KS, int STRIDE, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL>
+// F16 = true: half-precision operands on v_mfma_f32_32x32x16_f16 (f32 accumulate).  An f16 NHWC tensor
+// is addressed as a float tensor of channel PAIRS, which makes the whole data path -- patch geometry
+// (64 f16 = 128 B per pixel per chunk), weight pieces (1 KB per k-block x 32 couts), LDS-DMA, fragment
+// reads (16 B per lane) -- byte-identical to the f32 path: ConvParams counts channels in 4-byte units.
+// Only the MFMA (one K=16 instruction per 16-B fragment pair instead of four K=2), the epilogue store
+// and the conv1_1 row builder differ.
+template <int KS, int STRIDE, int TH, int TW, int WM, int WN, int MT, int NT, bool POOL, bool F16>
 HP3D_KERNEL(64 * WM * WN)
 void conv_mfma_kernel(const ConvParams p) {
     using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;
@@ -172,13 +178,21 @@ void conv_mfma_kernel(const ConvParams p) {
             fb[set][nt] = *(const f32x4*)(wbuf + bbase + (bufidx * C::WBUF_FLOATS + g * (BN * 8) + nt * 256));
     };
     auto mfma_group = [&](int set) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
+        if constexpr (F16) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = HP3D_MFMA_32x32x2(fa[set][mt][j], fb[set][nt][j], acc[mt][nt]);
+                    acc[mt][nt] = HP3D_MFMA_32x32x16_F16(fa[set][mt], fb[set][nt], acc[mt][nt]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = HP3D_MFMA_32x32x2(fa[set][mt][j], fb[set][nt][j], acc[mt][nt]);
+        }
     };
     auto tap_off = [&](int tap) {
         const int r = tap / KS, s = tap - r * KS;
@@ -245,13 +259,23 @@ void conv_mfma_kernel(const ConvParams p) {
         for (int idx = tid; idx < PH * PW * 8; idx += NTHR) {
             const int pix = idx >> 3, c4 = idx & 7;
             const int py = pix / PW, px = pix - py * PW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16) {
+                f16x8 v;                                  // 16-B slot c4 = f16 channels 8*c4 .. 8*c4+7 of 64
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = c4 * 4 + e;                 // k = (r*3+s)*3 + c
-                if (k < 27) v[e] = raw[((py + k / 9) * RW + px + (k / 3) % 3) * 3 + k % 3];
+                for (int e = 0; e < 8; ++e) {
+                    const int k = c4 * 8 + e;             // k = (r*3+s)*3 + c
+                    v[e] = (k < 27) ? (hp3d_f16)raw[((py + k / 9) * RW + px + (k / 3) % 3) * 3 + k % 3] : (hp3d_f16)0.f;
+                }
+                *(f16x8*)(patch + pix * LDA + c4 * 4) = v;
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = c4 * 4 + e;             // k = (r*3+s)*3 + c
+                    if (k < 27) v[e] = raw[((py + k / 9) * RW + px + (k / 3) % 3) * 3 + k % 3];
+                }
+                *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
             }
-            *(f32x4*)(patch + pix * LDA + c4 * 4) = v;
         }
     }
     }
@@ -298,7 +322,13 @@ void conv_mfma_kernel(const ConvParams p) {
         }
         return;
     }
-    float* outb = p.out + (size_t)b * Hs * Ws * p.out_cs;
+    // out_cs / cout_store count OUTPUT ELEMENTS here (f16 elements when the layer stores halves)
+    const bool store_h = F16 && !p.out_f32;
+    float* outb = p.out + (size_t)b * Hs * Ws * (store_h ? p.out_cs / 2 : p.out_cs);
+    hp3d_f16* outh = (hp3d_f16*)outb;
+    auto store = [&](size_t idx, float v) {
+        if (store_h) outh[idx] = (hp3d_f16)v; else outb[idx] = v;
+    };
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int co = n0 + (wn * NT + nt) * 32 + li;
@@ -321,12 +351,12 @@ void conv_mfma_kernel(const ConvParams p) {
                 if (POOL) {
                     const int y = (oy0 + t * ROWS_PER_MT + 2 * qy) >> 1, x = (ox0 + 2 * qx) >> 1;
                     const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                    if (cok && y < Hs && x < Ws) outb[((size_t)y * Ws + x) * p.out_cs + co] = m;
+                    if (cok && y < Hs && x < Ws) store(((size_t)y * Ws + x) * p.out_cs + co, m);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const int y = oy0 + t * ROWS_PER_MT + 2 * qy + (e >> 1), x = ox0 + 2 * qx + (e & 1);
-                        if (cok && y < Hs && x < Ws) outb[((size_t)y * Ws + x) * p.out_cs + co] = v[e];
+                        if (cok && y < Hs && x < Ws) store(((size_t)y * Ws + x) * p.out_cs + co, v[e]);
                     }
                 }
             }
@@ -336,12 +366,12 @@ void conv_mfma_kernel(const ConvParams p) {
 
 // ---- instantiation table -----------------------------------------------------------------
 // tile configs: id 0: 8x16 x128  1: 8x16 x64  2: 8x16 x32  3: 8x8 x128  4: 8x8 x64  5: 8x8 x32
-template <int KS, int STRIDE, bool POOL>
+template <int KS, int STRIDE, bool POOL, bool F16>
 int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
 #define HP3D_CASE(id, TH, TW, WM, WN, MT, NT)                                                        \
     case id: {                                                                                       \
         using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;                                        \
-        auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, WM, WN, MT, NT, POOL>;                       \
+        auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, WM, WN, MT, NT, POOL, F16>;                       \
         static bool attr_done = false, attr_done2 = false;                                          \
         if (!attr_done) {                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
@@ -417,11 +447,18 @@ int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cin, int Cout, int poo
 int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s) {
     const int cfg = plan.variant;
     if (cfg < 0 || cfg > 5 || kCfgTW[cfg] != plan.tw || kCfgBN[cfg] != plan.bn) return -1;
-    if (k == 1 && stride == 1 && !pool) return launch_cfg<1, 1, false>(p, cfg, s);
-    if (k == 3 && stride == 1 && !pool) return launch_cfg<3, 1, false>(p, cfg, s);
-    if (k == 3 && stride == 1 && pool) return launch_cfg<3, 1, true>(p, cfg, s);
-    if (k == 3 && stride == 2 && !pool) return launch_cfg<3, 2, false>(p, cfg, s);
-    if (k == 7 && stride == 1 && !pool) return launch_cfg<7, 1, false>(p, cfg, s);
+    if (p.f16) {      // half-precision trunk layers (no stride-2 layer runs in f16)
+        if (k == 1 && stride == 1 && !pool) return launch_cfg<1, 1, false, true>(p, cfg, s);
+        if (k == 3 && stride == 1 && !pool) return launch_cfg<3, 1, false, true>(p, cfg, s);
+        if (k == 3 && stride == 1 && pool) return launch_cfg<3, 1, true, true>(p, cfg, s);
+        if (k == 7 && stride == 1 && !pool) return launch_cfg<7, 1, false, true>(p, cfg, s);
+        return -1;
+    }
+    if (k == 1 && stride == 1 && !pool) return launch_cfg<1, 1, false, false>(p, cfg, s);
+    if (k == 3 && stride == 1 && !pool) return launch_cfg<3, 1, false, false>(p, cfg, s);
+    if (k == 3 && stride == 1 && pool) return launch_cfg<3, 1, true, false>(p, cfg, s);
+    if (k == 3 && stride == 2 && !pool) return launch_cfg<3, 2, false, false>(p, cfg, s);
+    if (k == 7 && stride == 1 && !pool) return launch_cfg<7, 1, false, false>(p, cfg, s);
     return -1;
 }
 

@@ -44,6 +44,8 @@ struct ConvL {
     // packed geometry
     int ek, cin_pad, cout_pad;
     size_t w_off, b_off;   // offsets into the blob (floats)
+    int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
+    size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
     int net;
 };
 struct FcL {
@@ -59,7 +61,7 @@ struct Tables {
     std::vector<ConvL> conv;
     std::vector<FcL> fc;
     std::map<std::string, int> conv_idx, fc_idx;
-    size_t blob_floats = 0;
+    size_t blob_floats = 0, blob16_halves = 0;
 
     void add_conv(const char* scope, const char* name, int k, int cin, int cout, int stride, int relu, int net) {
         ConvL l;
@@ -73,6 +75,11 @@ struct Tables {
         blob_floats += (size_t)l.ek * l.ek * l.cin_pad * l.cout_pad;
         l.b_off = blob_floats;
         blob_floats += l.cout_pad;
+        if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
+            l.cin_pad16 = (l.mode == 1) ? 64 : (l.mode == 2) ? 192 : (cin + 63) / 64 * 64;
+            l.w16_off = blob16_halves;
+            blob16_halves += (size_t)l.ek * l.ek * l.cin_pad16 * l.cout_pad;
+        }
         conv_idx[l.name] = (int)conv.size();
         conv.push_back(l);
     }
@@ -186,6 +193,10 @@ struct hp3d_ctx {
     Tables T;
     std::map<std::string, HostVar> vars;
     float* blob = nullptr;     // device, T.blob_floats
+    hp3d_f16* blob16 = nullptr; // device, T.blob16_halves (dtype 1 only)
+    int prec = 0;              // 0: f32 everywhere; 1: HandSegNet / PoseNet2D trunks in f16 (f32 accumulate)
+    hp3d_f16* d_concat16 = nullptr;
+    size_t concat16_px = 0;
     int nets = 0;              // finalized nets mask
     int empty_fltmax = 0;
     int conv_naive = 0;
@@ -291,6 +302,25 @@ void pack_conv(const ConvL& l, const float* w, const float* b, float* blob) {
         }
 }
 
+// half-precision packing: wpk16[tap][Cin/16][Cout/32][h][n][8] = W[tap][ref_channel(16*kb + 8*h + e)][32*co32 + n]
+void pack_conv16(const ConvL& l, const float* w, hp3d_f16* blob16) {
+    hp3d_f16* wp = blob16 + l.w16_off;
+    const int taps = l.ek * l.ek, KB = l.cin_pad16 / 16, CO32 = l.cout_pad / 32;
+    for (size_t i = 0; i < (size_t)taps * l.cin_pad16 * l.cout_pad; ++i) wp[i] = (hp3d_f16)0.f;
+    for (int tap = 0; tap < taps; ++tap)
+        for (int e16 = 0; e16 < l.cin_pad16; ++e16) {
+            int rtap = tap, rc = -1;
+            if (l.mode == 0) rc = (e16 < l.cin) ? e16 : -1;
+            else if (l.mode == 1) { if (e16 < 27) { rtap = e16 / 3; rc = e16 % 3; } }
+            else { if (e16 < 128) rc = 21 + e16; else if (e16 < 149) rc = e16 - 128; }
+            if (rc < 0) continue;
+            const int kb = e16 >> 4, h = (e16 >> 3) & 1, e = e16 & 7;
+            const float* src = w + ((size_t)rtap * l.cin + rc) * l.cout;
+            for (int co = 0; co < l.cout; ++co)
+                wp[((((size_t)tap * KB + kb) * CO32 + (co >> 5)) * 2 + h) * 256 + (co & 31) * 8 + e] = (hp3d_f16)src[co];
+        }
+}
+
 int find_var(hp3d_ctx* ctx, const std::string& name, const HostVar** out) {
     auto it = ctx->vars.find(name);
     if (it == ctx->vars.end()) return -1;
@@ -353,6 +383,8 @@ int ensure_pose_bufs(hp3d_ctx* ctx, int B, int hs, int ws) {
     if (px > ctx->pose_px || !ctx->d_concat) {
         CHK(dev_realloc(ctx, &ctx->d_concat, px * 160));
         for (int i = 0; i < 3; ++i) CHK(dev_realloc(ctx, &ctx->d_sm[i], px * 32));
+        CHK(dev_realloc(ctx, &ctx->d_concat16, px * 192));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_concat16, 0, px * 192 * sizeof(hp3d_f16), ctx->stream));
         ctx->pose_px = px;
     }
     return 0;
@@ -367,24 +399,27 @@ void same_pad(int in, int k, int stride, int* out, int* before) {
 
 // ---- one convolution layer -------------------------------------------------------------------
 // in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
+// f16 = 1 (trunk nets after hp3d_finalize_weights(dtype=1)): `in` / `out` hold halves (except the raw image of
+// conv1_1 and out_f32 heads); in_cs / out_cs are then counted in ELEMENTS of the respective tensor.
 int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, int H, int W, float* out, int out_cs,
-             int pool, int* Ho_out, int* Wo_out) {
+             int pool, int* Ho_out, int* Wo_out, int f16 = 0, int out_f32 = 0) {
     int Ho, Wo, pt, pl;
     const int k = l.ek;
     same_pad(H, k, l.stride, &Ho, &pt);
     same_pad(W, k, l.stride, &Wo, &pl);
     const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
-    const double bytes = 4.0 * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
+    const double bytes = (f16 ? 2.0 : 4.0) * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
                                 (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
-    if (ctx->conv_naive && l.mode == 0 && !pool) {
+    if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
         conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
                           l.relu, out, out_cs, Ho, Wo, pt, pl, ctx->stream);
     } else {
         ConvPlan plan;
-        if (conv_mfma_plan(k, l.stride, Ho, Wo, l.cin_pad, l.cout_pad, pool, B, &plan) != 0)
+        const int cin_units = f16 ? l.cin_pad16 / 2 : l.cin_pad;       // 4-byte channel units the kernel iterates
+        if (conv_mfma_plan(k, l.stride, Ho, Wo, cin_units, l.cout_pad, pool, B, &plan) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no conv_mfma variant for %s (k=%d s=%d)", l.name.c_str(), k, l.stride);
-        if (l.mode == 1) plan.ksplit = 1;
+        if (l.mode == 1 || (f16 && !out_f32)) plan.ksplit = 1;          // split-K partials are float32
         if (plan.ksplit > 1) {
             const size_t need = (size_t)plan.ksplit * B * Ho * Wo * l.cout_pad;
             if (need > ctx->col_floats) {
@@ -394,15 +429,19 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
             }
         }
         ConvParams p;
-        p.in = in; p.wpk = ctx->blob + l.w_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.in = in; p.wpk = f16 ? (const float*)(ctx->blob16 + l.w16_off) : ctx->blob + l.w_off;
+        p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
-        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.Cin = cin_units; p.in_cs = (f16 && l.mode != 1) ? in_cs / 2 : in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.f16 = f16; p.out_f32 = out_f32;
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
         p.act = l.relu; p.im2col = (l.mode == 1);
         p.ksplit = plan.ksplit; p.partial = ctx->col;
-        ProfScope ps(ctx, l.name, conv_mfma_variant_name(k, l.stride, pool, plan), flops, bytes);
+        std::string kname = conv_mfma_variant_name(k, l.stride, pool, plan);
+        if (f16) kname += "_f16";
+        ProfScope ps(ctx, l.name, kname.c_str(), flops, bytes);
         if (conv_mfma_launch(p, k, l.stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed for %s", l.name.c_str());
         if (plan.ksplit > 1)
@@ -425,16 +464,17 @@ int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H
     char nm[64];
     float* a = ctx->bufA;
     float* b = ctx->bufB;
+    const int f16 = ctx->prec;        // activations below are halves when set (same buffers, half the bytes)
     int ch = 64, ih = H, iw = W;
     snprintf(nm, sizeof nm, "%s/conv1_1", scope);
-    CHK(run_conv(ctx, CL(ctx, nm), image, 3, B, ih, iw, a, 64, 0, nullptr, nullptr));   // im2col fused in the loader
+    CHK(run_conv(ctx, CL(ctx, nm), image, 3, B, ih, iw, a, 64, 0, nullptr, nullptr, f16));   // im2col fused in the loader
     const int nl[4] = {2, 2, 4, n4}, chs[4] = {64, 128, 256, 512};
     for (int blk = 0; blk < 4; ++blk) {
         for (int i = (blk == 0 ? 1 : 0); i < nl[blk]; ++i) {
             snprintf(nm, sizeof nm, "%s/conv%d_%d", scope, blk + 1, i + 1);
             const int pool = (blk < 3 && i == nl[blk] - 1) ? 1 : 0;
             int oh, ow;
-            CHK(run_conv(ctx, CL(ctx, nm), a, ch, B, ih, iw, b, chs[blk], pool, &oh, &ow));
+            CHK(run_conv(ctx, CL(ctx, nm), a, ch, B, ih, iw, b, chs[blk], pool, &oh, &ow, f16));
             std::swap(a, b);
             ch = chs[blk]; ih = oh; iw = ow;
         }
@@ -448,10 +488,12 @@ int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W) {
     float* a; int h, w;
     CHK(run_trunk(ctx, "HandSegNet", image, B, H, W, 4, &a, &h, &w));
     float* b = (a == ctx->bufA) ? ctx->bufB : ctx->bufA;
-    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_1"), a, 512, B, h, w, b, 512, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_2"), b, 512, B, h, w, a, 128, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_1"), a, 128, B, h, w, b, 512, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_2"), b, 512, B, h, w, ctx->d_segsmall, 32, 0, nullptr, nullptr));
+    const int f16 = ctx->prec;
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_1"), a, 512, B, h, w, b, 512, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_2"), b, 512, B, h, w, a, 128, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_1"), a, 128, B, h, w, b, 512, 0, nullptr, nullptr, f16));
+    // the 2-class head always leaves float32 logits for the softmax / mask stage
+    CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_2"), b, 512, B, h, w, ctx->d_segsmall, 32, 0, nullptr, nullptr, f16, 1));
     return 0;
 }
 
@@ -460,33 +502,39 @@ int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
     float* a; int h, w;
     CHK(run_trunk(ctx, "PoseNet2D", crop, B, H, W, 2, &a, &h, &w));
     CHK(ensure_pose_bufs(ctx, B, h, w));
+    const int f16 = ctx->prec;
+    // concat([scoremap, encoding]) buffer: f32 [B,h,w,160] or f16 [B,h,w,192] (64-half chunks); channel 0..127 =
+    // encoding, 128..148 = score map, rest zero (the f16 pad 160..191 is zeroed when the buffer is allocated)
+    const int ccs = f16 ? 192 : 160;
+    float* cat = f16 ? (float*)ctx->d_concat16 : ctx->d_concat;
     float* b = (a == ctx->bufA) ? ctx->bufB : ctx->bufA;
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_3"), a, 512, B, h, w, b, 256, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_4"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_5"), a, 256, B, h, w, b, 256, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_6"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr));
-    // encoding -> channels 0..127 of the concat buffer [B,h,w,160]
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_7"), a, 256, B, h, w, ctx->d_concat, 160, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_1"), ctx->d_concat, 160, B, h, w, a, 512, 0, nullptr, nullptr));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_2"), a, 512, B, h, w, ctx->d_sm[0], 32, 0, nullptr, nullptr));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_3"), a, 512, B, h, w, b, 256, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_4"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_5"), a, 256, B, h, w, b, 256, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_6"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_7"), a, 256, B, h, w, cat, ccs, 0, nullptr, nullptr, f16));
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_1"), cat, ccs, B, h, w, a, 512, 0, nullptr, nullptr, f16));
+    // score-map heads always store float32 [.,32] (they feed the lifting nets, the up-sampler and the caller)
+    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_2"), a, 512, B, h, w, ctx->d_sm[0], 32, 0, nullptr, nullptr, f16, 1));
     char nm[64];
     const int npix = B * h * w;
     for (int p = 0; p < 2; ++p) {
         // x = concat([scoremap, encoding]) : scoremap (21 real + 11 zero) -> channels 128..159
-        copy_channels_launch(ctx->d_sm[p], npix, 32, 32, ctx->d_concat + 128, 160, ctx->stream);
-        const float* x = ctx->d_concat;
-        int xcs = 160;
+        if (f16) cvt_channels_f16_launch(ctx->d_sm[p], npix, 32, 32, ctx->d_concat16 + 128, 192, ctx->stream);
+        else copy_channels_launch(ctx->d_sm[p], npix, 32, 32, ctx->d_concat + 128, 160, ctx->stream);
+        const float* x = cat;
+        int xcs = ccs;
         float* o = a;
         for (int r = 1; r <= 5; ++r) {
             snprintf(nm, sizeof nm, "PoseNet2D/conv%d_%d", p + 6, r);
-            CHK(run_conv(ctx, CL(ctx, nm), x, xcs, B, h, w, o, 128, 0, nullptr, nullptr));
+            CHK(run_conv(ctx, CL(ctx, nm), x, xcs, B, h, w, o, 128, 0, nullptr, nullptr, f16));
             x = o; xcs = 128;
             o = (o == a) ? b : a;
         }
         snprintf(nm, sizeof nm, "PoseNet2D/conv%d_6", p + 6);
-        CHK(run_conv(ctx, CL(ctx, nm), x, 128, B, h, w, o, 128, 0, nullptr, nullptr));
+        CHK(run_conv(ctx, CL(ctx, nm), x, 128, B, h, w, o, 128, 0, nullptr, nullptr, f16));
         snprintf(nm, sizeof nm, "PoseNet2D/conv%d_7", p + 6);
-        CHK(run_conv(ctx, CL(ctx, nm), o, 128, B, h, w, ctx->d_sm[p + 1], 32, 0, nullptr, nullptr));
+        CHK(run_conv(ctx, CL(ctx, nm), o, 128, B, h, w, ctx->d_sm[p + 1], 32, 0, nullptr, nullptr, f16, 1));
     }
     return 0;
 }
@@ -764,6 +812,8 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
     if (ctx->d_u8) hipFree(ctx->d_u8);
+    if (ctx->blob16) hipFree(ctx->blob16);
+    if (ctx->d_concat16) hipFree(ctx->d_concat16);
     for (auto& kv : ctx->naive_w) hipFree(kv.second);
     for (hipEvent_t e : ctx->event_pool) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -834,7 +884,7 @@ int hp3d_set_weight(hp3d_ctx* ctx, const char* tf_var_name, const float* data, c
 
 int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     if (!ctx) return HP3D_ERR_ARG;
-    if (dtype != 0) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "only dtype 0 (f32) is implemented");
+    if (dtype != 0 && dtype != 1) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "dtype must be 0 (f32) or 1 (f16 trunks)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     std::vector<float> host(ctx->T.blob_floats, 0.f);
     int have = 0, partial = 0, bn_ok = 0;
@@ -884,6 +934,17 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     HIPCHK(ctx, hipMemcpy(ctx->blob, host.data(), sizeof(float) * ctx->T.blob_floats, hipMemcpyHostToDevice));
     ctx->nets = have & ~partial;
     if (bn_ok == 2) ctx->nets |= NET_BOTTLENECK;
+    ctx->prec = dtype;
+    if (dtype == 1) {    // half-precision copies of the HandSegNet / PoseNet2D filters (biases, heads' outputs and the lifting nets stay f32)
+        std::vector<hp3d_f16> h16(ctx->T.blob16_halves, (hp3d_f16)0.f);
+        for (const ConvL& l : ctx->T.conv) {
+            if (!(l.net == NET_SEG || l.net == NET_POSE) || !(ctx->nets & l.net)) continue;
+            const HostVar* w = nullptr;
+            if (find_var(ctx, l.name + "/weights", &w) == 0) pack_conv16(l, w->data.data(), h16.data());
+        }
+        if (!ctx->blob16) CHK(dev_realloc(ctx, &ctx->blob16, ctx->T.blob16_halves));
+        HIPCHK(ctx, hipMemcpy(ctx->blob16, h16.data(), sizeof(hp3d_f16) * ctx->T.blob16_halves, hipMemcpyHostToDevice));
+    }
     // raw HWIO copies for the debug conv (conv_impl=naive)
     if (ctx->conv_naive)
         for (const ConvL& l : ctx->T.conv) {
@@ -898,28 +959,41 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     return 0;
 }
 
+// blob = [float32 section (all nets) | float16 section (trunk filters, always reserved so every rank agrees on the size)]
 int hp3d_weights_blob_bytes(hp3d_ctx* ctx, size_t* bytes) {
     if (!ctx || !bytes) return HP3D_ERR_ARG;
-    *bytes = ctx->T.blob_floats * sizeof(float);
+    *bytes = ctx->T.blob_floats * sizeof(float) + ctx->T.blob16_halves * sizeof(hp3d_f16);
     return 0;
 }
 int hp3d_weights_blob_export(hp3d_ctx* ctx, void* dev_dst) {
     if (!ctx || !dev_dst) return HP3D_ERR_ARG;
     if (!ctx->blob) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "weights not finalized");
-    HIPCHK(ctx, hipMemcpyAsync(dev_dst, ctx->blob, ctx->T.blob_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t n32 = ctx->T.blob_floats * sizeof(float), n16 = ctx->T.blob16_halves * sizeof(hp3d_f16);
+    HIPCHK(ctx, hipMemcpyAsync(dev_dst, ctx->blob, n32, hipMemcpyDeviceToDevice, ctx->stream));
+    if (ctx->blob16)
+        HIPCHK(ctx, hipMemcpyAsync((char*)dev_dst + n32, ctx->blob16, n16, hipMemcpyDeviceToDevice, ctx->stream));
+    else
+        HIPCHK(ctx, hipMemsetAsync((char*)dev_dst + n32, 0, n16, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 int hp3d_weights_blob_import(hp3d_ctx* ctx, const void* dev_src, int nets_mask) {
     if (!ctx || !dev_src) return HP3D_ERR_ARG;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const size_t n32 = ctx->T.blob_floats * sizeof(float), n16 = ctx->T.blob16_halves * sizeof(hp3d_f16);
     if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->blob, dev_src, ctx->T.blob_floats * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->blob, dev_src, n32, hipMemcpyDeviceToDevice, ctx->stream));
+    const int f16 = (nets_mask & 32) ? 1 : 0;     // bit 5: the half-precision section is live (dtype 1)
+    if (f16) {
+        if (!ctx->blob16) CHK(dev_realloc(ctx, &ctx->blob16, ctx->T.blob16_halves));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->blob16, (const char*)dev_src + n32, n16, hipMemcpyDeviceToDevice, ctx->stream));
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->nets = nets_mask;
+    ctx->nets = nets_mask & 31;
+    ctx->prec = f16;
     return 0;
 }
-int hp3d_nets_mask(hp3d_ctx* ctx) { return ctx ? ctx->nets : 0; }
+int hp3d_nets_mask(hp3d_ctx* ctx) { return ctx ? (ctx->nets | (ctx->prec ? 32 : 0)) : 0; }
 
 int hp3d_infer_full(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                     float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
@@ -1090,7 +1164,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = act; p.im2col = 0;
+        p.act = act; p.im2col = 0; p.f16 = 0; p.out_f32 = 0;
         p.ksplit = plan.ksplit; p.partial = d_part;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");

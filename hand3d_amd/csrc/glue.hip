@@ -221,6 +221,17 @@ void copy_channels_kernel(const float* in, long npix, int C, int in_cs, float* o
     }
 }
 
+// float32 [npix, in_cs] channels 0..C-1 -> half [npix, out_cs] (score map fed back into the f16 concat buffer)
+HP3D_KERNEL(256)
+void cvt_channels_f16_kernel(const float* in, long npix, int C, int in_cs, hp3d_f16* out, int out_cs) {
+    const long total = npix * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const long p = i / C;
+        out[p * out_cs + c] = (hp3d_f16)in[p * in_cs + c];
+    }
+}
+
 // [npix, C] -> [npix, out_cs] zero padded
 HP3D_KERNEL(256)
 void pad_channels_kernel(const float* in, long npix, int C, float* out, int out_cs) {
@@ -648,6 +659,10 @@ void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const 
 }
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s) {
     HP3D_LAUNCH(copy_channels_kernel, dim3(grid_for((long)npix * C)), dim3(256), 0, s, in, (long)npix, C, in_cs, out,
+                out_cs);
+}
+void cvt_channels_f16_launch(const float* in, int npix, int C, int in_cs, hp3d_f16* out, int out_cs, hipStream_t s) {
+    HP3D_LAUNCH(cvt_channels_f16_kernel, dim3(grid_for((long)npix * C)), dim3(256), 0, s, in, (long)npix, C, in_cs, out,
                 out_cs);
 }
 void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s) {

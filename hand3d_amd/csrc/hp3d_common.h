@@ -13,10 +13,15 @@
 #include <hip/hip_runtime.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 hp3d_f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define HP3D_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
 #define HP3D_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 #define HP3D_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// 16-B fragments (held as f32x4) reinterpreted as 8 halves: lane l carries k = 8*(l>>5) .. 8*(l>>5)+7
+#define HP3D_MFMA_32x32x16_F16(a, b, c) \
+    __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define HP3D_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
@@ -59,6 +64,8 @@ struct ConvParams {
     int act;              // HP3D_ACT_*
     int ksplit;           // >1: split-K over grid.z, raw partial sums go to `partial`
     float* partial;       // [ksplit][B*Ho*Wo][Cout]
+    int f16;              // 1: half-precision operands (channel counts/strides above are in 4-byte units = f16 pairs)
+    int out_f32;          // f16 mode only: store float32 (score-map heads) instead of halves
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
 };
 
@@ -114,4 +121,5 @@ void lift_epilogue_launch(const float* u, const float* coord_can, const float* h
 void bone_rel_inv_launch(const float* rel, int B, float* xyz, hipStream_t s);   // [B,21,3] local -> xyz
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s);
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s);
+void cvt_channels_f16_launch(const float* in, int npix, int C, int in_cs, hp3d_f16* out, int out_cs, hipStream_t s);
 void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s);

@@ -57,17 +57,17 @@ class ShardedPipeline(object):
     def __init__(self, engine, rank=0, world=1, group=None):
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
 
-    def sync_weights(self, weights=None, device=None):
+    def sync_weights(self, weights=None, device=None, dtype=0):
         import torch
         from . import _lib
-        full = _lib.NET_SEG | _lib.NET_POSE | _lib.NET_PRIOR | _lib.NET_VP
+        full = _lib.NET_SEG | _lib.NET_POSE | _lib.NET_PRIOR | _lib.NET_VP | (32 if dtype in (1, 'f16') else 0)
         if self.rank == 0:
             self.engine.load_weight_dict(weights)
-            self.engine.finalize_weights()
+            self.engine.finalize_weights(dtype)
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return
-        n = self.engine.blob_bytes() // 4
+        n = (self.engine.blob_bytes() + 3) // 4
         blob = torch.empty(n, dtype=torch.float32, device=device)
         if self.rank == 0:
             self.engine.blob_export(blob.data_ptr())

@@ -53,10 +53,11 @@ class ColorHandPose3DNetwork(object):
             weight_files = ['./weights/handsegnet-rhd.pickle', './weights/posenet3d-rhd-stb-slr-finetuned.pickle']
         load_weight_files(self.engine, weight_files, exclude_var_list)
 
-    def init_from_dict(self, weight_dict):
-        """Convenience for synthetic weights: the merged content of the weight files."""
+    def init_from_dict(self, weight_dict, dtype=0):
+        """Convenience for synthetic weights: the merged content of the weight files.
+        dtype='f16' selects the half-precision trunks (BASELINE config 5)."""
         self.engine.load_weight_dict(weight_dict)
-        self.engine.finalize_weights()
+        self.engine.finalize_weights(dtype)
 
     @staticmethod
     def _check_eval(evaluation):

@@ -70,14 +70,17 @@ int hp3d_set_weight(hp3d_ctx* ctx, const char* tf_var_name, const float* data,
                     const int64_t* shape, int rank);
 /* Pack everything set so far for the device (repack HWIO -> MFMA fragment order, permute
  * the concat channels of conv6_1/conv7_1, upload).  Nets whose variables are all present
- * become runnable; a net with only some of its variables is an error.  dtype: 0 = f32.      */
+ * become runnable; a net with only some of its variables is an error.
+ * dtype 0: float32 everywhere (exact f32 MFMA).  dtype 1 (BASELINE config 5): the HandSegNet / PoseNet2D
+ * filters and activations are float16 on v_mfma_f32_32x32x16_f16 with float32 accumulation, biases and
+ * score-map heads; the lifting nets, the mask stage and all outputs stay float32.                   */
 int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype);
 /* The packed device blob (identical layout on every rank): size, export to / import from a
  * device buffer.  Used for the one-off RCCL broadcast of weights (bench.py, N>1).           */
 int hp3d_weights_blob_bytes(hp3d_ctx* ctx, size_t* bytes);
 int hp3d_weights_blob_export(hp3d_ctx* ctx, void* dev_dst);
 int hp3d_weights_blob_import(hp3d_ctx* ctx, const void* dev_src, int nets_mask);
-int hp3d_nets_mask(hp3d_ctx* ctx);   /* bit0 HandSegNet, bit1 PoseNet2D, bit2 PosePrior, bit3 ViewpointNet, bit4 bottleneck */
+int hp3d_nets_mask(hp3d_ctx* ctx);   /* bit0 HandSegNet, bit1 PoseNet2D, bit2 PosePrior, bit3 ViewpointNet, bit4 bottleneck, bit5 f16 trunks */
 
 /* ---- whole-path entry points ------------------------------------------------------------
  * hp3d_infer_full   replaces ColorHandPose3DNetwork.inference (nets/ColorHandPose3DNetwork.py:61-99)

@@ -14,8 +14,13 @@ F32 = np.float32
 class _Ops:
     """NetworkOps of utils/general.py:26-65,112-148 bound to a weight dict and a scope."""
 
-    def __init__(self, weights, scope, acc=np.float32, taps=None):
-        self.w, self.scope, self.acc, self.taps = weights, scope, acc, taps
+    def __init__(self, weights, scope, acc=np.float32, taps=None, f16=False):
+        self.w, self.scope, self.acc, self.taps, self.f16 = weights, scope, acc, taps, f16
+
+    @staticmethod
+    def _h(x):
+        """round-trip through float16: what a half-precision tensor in HBM holds"""
+        return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
 
     def _tap(self, name, x):
         if self.taps is not None:
@@ -25,11 +30,15 @@ class _Ops:
         w = self.w['%s/%s/weights' % (self.scope, name)]
         b = self.w['%s/%s/biases' % (self.scope, name)]
         assert w.shape == (kernel_size, kernel_size, x.shape[3], out_chan), (name, w.shape, x.shape)
+        if self.f16:      # engine dtype 1: half operands, float32 accumulate + bias (include/hp3d.h)
+            x, w = self._h(x), self._h(w)
         y = T.bias_add(T.conv2d_same(x, w, stride, acc=self.acc), b)
         return y
 
     def conv_relu(self, x, name, kernel_size, stride, out_chan):
         y = T.leaky_relu(self.conv(x, name, kernel_size, stride, out_chan))
+        if self.f16:
+            y = self._h(y)          # activations are stored as halves; heads (conv_lin) stay float32
         self._tap(name, y)
         return y
 
@@ -57,10 +66,10 @@ class _Ops:
         return y
 
 
-def handsegnet(weights, image, acc=np.float32, taps=None):
+def handsegnet(weights, image, acc=np.float32, taps=None, f16=False):
     """ColorHandPose3DNetwork.inference_detection -- nets/ColorHandPose3DNetwork.py:131-168.
     Returns (scoremap_small [B,H/8,W/8,2], [scoremap_large [B,H,W,2]])."""
-    ops = _Ops(weights, 'HandSegNet', acc, taps)
+    ops = _Ops(weights, 'HandSegNet', acc, taps, f16)
     x = np.asarray(image, dtype=F32)
     for block_id, (n, c, pool) in enumerate(zip([2, 2, 4, 4], [64, 128, 256, 512], [True, True, True, False]), 1):
         for layer_id in range(n):
@@ -75,10 +84,10 @@ def handsegnet(weights, image, acc=np.float32, taps=None):
     return scoremap, [T.resize_bilinear_legacy(scoremap, H, W)]
 
 
-def posenet2d(weights, image_crop, acc=np.float32, taps=None, num_kp=21):
+def posenet2d(weights, image_crop, acc=np.float32, taps=None, num_kp=21, f16=False):
     """ColorHandPose3DNetwork.inference_pose2d -- nets/ColorHandPose3DNetwork.py:170-219.
     Returns the list of 3 scoremaps [B,h/8,w/8,21]."""
-    ops = _Ops(weights, 'PoseNet2D', acc, taps)
+    ops = _Ops(weights, 'PoseNet2D', acc, taps, f16)
     x = np.asarray(image_crop, dtype=F32)
     for block_id, (n, c, pool) in enumerate(zip([2, 2, 4, 2], [64, 128, 256, 512], [True, True, True, False]), 1):
         for layer_id in range(n):
@@ -176,12 +185,12 @@ def pose3d(weights, scoremap32, hand_side, acc=np.float32, taps=None):
     return rel, can, R
 
 
-def inference(weights, image, hand_side, evaluation=True, acc=np.float32, taps=None, crop_size=256):
+def inference(weights, image, hand_side, evaluation=True, acc=np.float32, taps=None, crop_size=256, f16=False):
     """ColorHandPose3DNetwork.inference -- nets/ColorHandPose3DNetwork.py:61-99.
     Returns (hand_scoremap, image_crop, scale_crop, center, keypoints_scoremap, keypoint_coord3d)."""
     assert evaluation, "the oracle restates the evaluation graph only (dropout == identity)"
     image = np.asarray(image, dtype=F32)
-    _, large = handsegnet(weights, image, acc, taps)
+    _, large = handsegnet(weights, image, acc, taps, f16)
     hand_scoremap = large[-1]
     hand_mask = G.single_obj_scoremap(hand_scoremap, early_exit=True)
     center, _, crop_size_best = G.calc_center_bb(hand_mask)
@@ -189,7 +198,7 @@ def inference(weights, image, hand_side, evaluation=True, acc=np.float32, taps=N
     image_crop = G.crop_image_from_xy(image, center, crop_size, scale=scale_crop)
     if taps is not None:
         taps['hand_mask'] = hand_mask
-    sm32 = posenet2d(weights, image_crop, acc, taps)[-1]
+    sm32 = posenet2d(weights, image_crop, acc, taps, f16=f16)[-1]
     coord3d, _, _ = pose3d(weights, sm32, hand_side, acc, taps)
     kp_scoremap = T.resize_bilinear_legacy(sm32, crop_size, crop_size)
     return hand_scoremap, image_crop, scale_crop, center, kp_scoremap, coord3d

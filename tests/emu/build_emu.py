@@ -2,6 +2,7 @@
 import os
 import subprocess
 
+CXX = os.environ.get('HP3D_EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++' if os.path.exists('/opt/rocm/lib/llvm/bin/clang++') else 'g++')
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hand3d_amd', 'csrc')
@@ -17,12 +18,12 @@ def build(force=False):
     for s in SRCS:
         o = os.path.join(HERE, os.path.basename(s).rsplit('.', 1)[0] + '.emu.o')
         objs.append(o)
-        procs.append(subprocess.Popen(['g++', '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-DHP3D_EMU', '-ffp-contract=off',
+        procs.append(subprocess.Popen([CXX, '-x', 'c++', '-std=c++17', '-O2', '-fPIC', '-DHP3D_EMU', '-ffp-contract=off',
                                        '-fno-strict-aliasing', '-w', '-Wno-psabi', '-I', HERE, '-I', CSRC, '-c', s, '-o', o]))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError('emu build failed')
-    subprocess.check_call(['g++', '-shared', '-o', LIB] + objs)
+    subprocess.check_call([CXX, '-shared', '-o', LIB] + objs)
     return LIB
 
 

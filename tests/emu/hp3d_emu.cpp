@@ -44,6 +44,7 @@ struct Fiber {
 struct WaveX {
     int count = 0, gen = 0;
     float a[2][64], b[2][64];
+    f32x4 a4[2][64], b4[2][64];
     unsigned long long v[2][64];
 };
 
@@ -115,6 +116,32 @@ f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c) {
         float d = c[r];
         d = fmaf(w.a[slot][row], w.b[slot][col], d);
         d = fmaf(w.a[slot][row + 32], w.b[slot][col + 32], d);
+        c[r] = d;
+    }
+    return c;
+}
+
+f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c) {
+    const unsigned tid = g_blk.cur->tid;
+    WaveX& w = g_blk.waves[tid >> 6];
+    const int lane = tid & 63, slot = w.gen & 1;
+    w.a4[slot][lane] = a;
+    w.b4[slot][lane] = b;
+    wave_rendezvous(w, 64);
+    // v_mfma_f32_32x32x16_f16: A[i][k] in lane i + 32*(k/8), element k%8; B[k][j] likewise; D as 32x32x2.
+    // Products are exact in f32; accumulation is modelled in k order (the hardware's internal order is
+    // not specified -- tests use tolerances that cover it).
+    const int col = lane & 31, hi = lane >> 5;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float d = c[r];
+        for (int k = 0; k < 16; ++k) {
+            f32x4 av = w.a4[slot][row + 32 * (k >> 3)], bv = w.b4[slot][col + 32 * (k >> 3)];
+            _Float16 ah[8], bh[8];
+            memcpy(ah, &av, 16);
+            memcpy(bh, &bv, 16);
+            d += (float)ah[k & 7] * (float)bh[k & 7];
+        }
         c[r] = d;
     }
     return c;

@@ -18,6 +18,8 @@
 
 typedef float f32x4 __attribute__((vector_size(16)));
 typedef float f32x16 __attribute__((vector_size(64)));
+typedef _Float16 hp3d_f16;
+typedef _Float16 f16x8 __attribute__((vector_size(16)));
 
 struct dim3 {
     unsigned x, y, z;
@@ -66,6 +68,8 @@ void hp3d_emu_syncthreads();
 #define __syncthreads hp3d_emu_syncthreads
 f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
 #define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))
+f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
+#define HP3D_MFMA_32x32x16_F16(a, b, c) hp3d_emu_mfma_32x32x16_f16((a), (b), (c))
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }
 

@@ -130,3 +130,23 @@ def test_preprocess_u8_on_interpreter(emu_engine):
     assert np.array_equal(emu_engine.preprocess_u8(u8, 24, 32), G.preprocess_u8(u8, 24, 32))
     assert np.array_equal(emu_engine.preprocess_u8(u8, 48, 64), u8.astype(np.float32) / np.float32(255) - np.float32(0.5))
     assert np.array_equal(emu_engine.preprocess_u8(u8, 30, 50), G.preprocess_u8(u8, 30, 50))
+
+
+def test_f16_trunk_mode_on_interpreter(emu_engine, synth_weights):
+    """hp3d_finalize_weights(dtype=1): half-precision trunks (same kernel template, K=16 MFMA) vs the oracle with
+    the same rounding points; f32 heads; weights restored to f32 afterwards."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights, dtype='f16')
+    try:
+        assert emu_engine.nets_mask() & 32
+        img = synth.make_batch(3, 1, 16, 24)
+        _, small = emu_engine.handsegnet(img, want_small=True)
+        rs, _ = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
+        assert np.abs(small - rs).max() < 2e-3
+        crop = synth.make_batch(9, 1, 16, 16)
+        for a, b in zip(net.inference_pose2d(crop), N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)):
+            assert np.abs(a - b).max() < 2e-3
+    finally:
+        net.init_from_dict(synth_weights, dtype=0)
+    assert not (emu_engine.nets_mask() & 32)

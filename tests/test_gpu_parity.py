@@ -373,6 +373,46 @@ def test_golden_fixtures_gpu(net, synth_weights):
     assert np.abs(o[4][0, ::8, ::8, :] - g['scoremap32']).max() < TOL_HEATMAP
 
 
+def test_f16_trunks_config_c5(gpu_engine, synth_weights):
+    """BASELINE config 5 precision: half-precision HandSegNet / PoseNet2D trunks (v_mfma_f32_32x32x16_f16, f32
+    accumulate), float32 heads / mask stage / lifting.  Checked against the oracle with the same rounding points
+    (tight) and against the float32 oracle (the config's own looser tolerance: 5e-3 heat-maps)."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net16 = ColorHandPose3DNetwork(engine=gpu_engine)
+    net16.init_from_dict(synth_weights, dtype='f16')
+    try:
+        img = synth.make_batch(500, 2, 240, 320)
+        large, small = gpu_engine.handsegnet(img, want_small=True)
+        rs16, _ = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
+        rs32, _ = N.handsegnet(synth_weights, img, acc=np.float64)
+        e16, e32 = np.abs(small - rs16).max(), np.abs(small - rs32).max()
+        print("f16 HandSegNet logits: vs f16-rounding oracle %.3e, vs f32 oracle %.3e" % (e16, e32))
+        assert e16 < 2e-3 and e32 < 5e-3
+        crop = synth.make_batch(100, 1, 256, 256)
+        sms = net16.inference_pose2d(crop)
+        r16 = N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)
+        r32 = N.posenet2d(synth_weights, crop, acc=np.float64)
+        for a, b, c in zip(sms, r16, r32):
+            print("f16 PoseNet2D heat-map: vs f16-rounding oracle %.3e, vs f32 oracle %.3e" % (np.abs(a - b).max(), np.abs(a - c).max()))
+            assert np.abs(a - b).max() < 2e-3 and np.abs(a - c).max() < 5e-3
+        # whole path: runs, finite, and close to the float32 engine wherever the mask (hence the crop) agrees
+        hs = synth.hand_sides(2)
+        o16 = gpu_engine.infer_full(img, hs, want_mask=True)
+        gpu_engine.load_weight_dict(synth_weights)
+        gpu_engine.finalize_weights(0)
+        o32 = gpu_engine.infer_full(img, hs, want_mask=True)
+        iou = (np.logical_and(o16['mask'] > 0, o32['mask'] > 0).sum() + 1e-9) / (np.logical_or(o16['mask'] > 0, o32['mask'] > 0).sum() + 1e-9)
+        print("f16 vs f32 engine: mask IoU %.4f, |coord3d| diff %.3e" % (iou, np.abs(o16['coord3d'] - o32['coord3d']).max()))
+        assert np.isfinite(o16['coord3d']).all() and iou > 0.9   # random-weight logits hover near the threshold: edge pixels flip
+        for i in range(2):
+            if np.array_equal(o16['center'][i], o32['center'][i]) and np.array_equal(o16['scale'][i], o32['scale'][i]):
+                assert np.abs(o16['kpmap'][i] - o32['kpmap'][i]).max() < 5e-3
+                assert np.abs(o16['coord3d'][i] - o32['coord3d'][i]).max() < 5e-3
+    finally:
+        gpu_engine.load_weight_dict(synth_weights)
+        gpu_engine.finalize_weights(0)
+
+
 def test_errors_are_loud(gpu_engine):
     from hand3d_amd import ColorHandPose3DNetwork, Engine
     with pytest.raises(AssertionError):

@@ -38,7 +38,7 @@ def parse():
     ap.add_argument('--height', type=int, default=320)
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--workload', default='full', choices=['full', 'posenet'])
-    ap.add_argument('--cpu-images', type=int, default=3, help='oracle images timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-images', type=int, default=5, help='oracle images timed for cpu_baseline (0 = skip)')
     ap.add_argument('--layers', action='store_true', help='print the per-layer table to stderr')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'],
                     help="f32 = exact f32 MFMA (headline); f16 = half-precision trunks, BASELINE config 5 (looser parity)")
@@ -59,9 +59,17 @@ def cpu_baseline(weights, H, W, n_images, workload):
         else:
             onets.posenet2d(weights, imgs[i:i + 1])
     dt = time.time() - t0
-    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d image(s) of the same workload through the NumPy oracle (OpenBLAS, float32), %.1f s"
-                      % (n_images, dt)}
+    threads = os.cpu_count()
+    try:        # the GEMMs inside the oracle run on NumPy's BLAS pool: report the threads it really uses
+        from threadpoolctl import threadpool_info
+        blas = [p['num_threads'] for p in threadpool_info() if p.get('user_api') == 'blas']
+        if blas:
+            threads = max(blas)
+    except Exception:
+        pass
+    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": "%d image(s) of the same workload through the NumPy oracle (float32, BLAS pool of %d threads on a "
+                      "%d-core host), %.1f s" % (n_images, threads, os.cpu_count(), dt)}
 
 
 def main():

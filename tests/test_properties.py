@@ -1,0 +1,73 @@
+"""Property tests (hypothesis) on the CPU interpreter of the kernel sources: random geometries for the conv
+kernel, random detection maps for the seeded growth, random boxes for crop-and-resize -- always bit-exact or
+to rounding against the oracle."""
+import numpy as np
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import general as G
+from oracle import tf_ops as T
+
+COMMON = dict(deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
+
+
+@settings(max_examples=12, **COMMON)
+@given(H=st.integers(3, 20), W=st.integers(3, 20), Cin=st.integers(1, 40), Cout=st.integers(1, 70),
+       ks=st.sampled_from([(1, 1), (3, 1), (3, 2), (7, 1)]), B=st.integers(1, 2), seed=st.integers(0, 10 ** 6))
+def test_conv_random_geometry(emu_engine, H, W, Cin, Cout, ks, B, seed):
+    k, s = ks
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, s, acc=np.float64), b))
+    y = emu_engine.conv2d(x, w, b, s, True, False)
+    assert y.shape == r.shape and np.abs(y - r).max() < 2e-5
+    if k == 3 and s == 1 and H >= 2 and W >= 2:
+        assert np.abs(emu_engine.conv2d(x, w, b, 1, True, True) - T.max_pool_2x2(r)).max() < 2e-5
+
+
+@settings(max_examples=15, **COMMON)
+@given(H=st.integers(24, 72), W=st.integers(32, 96), density=st.floats(0.05, 0.95), seed=st.integers(0, 10 ** 6),
+       blocky=st.booleans())
+def test_mask_growth_random_maps(emu_engine, H, W, density, seed, blocky):
+    """det = random (optionally blocky) binary map; fg peaks at a random pixel.  Mask, seed, bbox, centre,
+    size and scale must be identical to the reference algorithm (full max(H,W)//10 passes, no early exit)."""
+    rng = np.random.default_rng(seed)
+    if blocky:
+        small = rng.uniform(size=(H // 6 + 1, W // 6 + 1)) < density
+        det = np.kron(small, np.ones((6, 6)))[:H, :W] > 0
+    else:
+        det = rng.uniform(size=(H, W)) < density
+    logit = np.where(det, rng.uniform(0.1, 3.0, size=(H, W)), rng.uniform(-3.0, -0.1, size=(H, W))).astype(np.float32)
+    sm = np.zeros((1, H, W, 2), np.float32)
+    sm[0, :, :, 1] = logit
+    mask, center, size, scale, seed_px = emu_engine.mask_from_scoremap(sm)
+    fg, d = G.fg_and_detmap(sm)
+    ref_seed = G.find_max_location(fg)
+    obj, _ = G.grow_objectmap(d[0], ref_seed[0], early_exit=False)
+    rc, _, rs = G.calc_center_bb(obj[None, :, :, None])
+    assert np.array_equal(seed_px, ref_seed)
+    assert np.array_equal(mask[0], obj)
+    assert np.array_equal(center, rc) and np.array_equal(size, rs)
+    assert np.array_equal(scale, G.scale_from_crop_size(rs))
+
+
+@settings(max_examples=20, **COMMON)
+@given(cy=st.floats(-20, 80), cx=st.floats(-20, 100), scale=st.floats(0.25, 5.0), seed=st.integers(0, 10 ** 6))
+def test_crop_random_boxes(emu_engine, cy, cx, scale, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.uniform(-.5, .5, (1, 48, 64, 3)).astype(np.float32)
+    c = np.array([[cy, cx]], np.float32)
+    s = np.array([scale], np.float32)
+    assert np.array_equal(emu_engine.crop_and_resize(img, c, s, 32), G.crop_image_from_xy(img, c, 32, s))
+
+
+@settings(max_examples=10, **COMMON)
+@given(B=st.integers(1, 40), Cin=st.integers(1, 300), Cout=st.integers(1, 130), seed=st.integers(0, 10 ** 6))
+def test_fc_random_shapes(emu_engine, B, Cin, Cout, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    assert np.abs(emu_engine.fc(x, w, b, False) - T.fully_connected(x, w, b, np.float64)).max() < 1e-5

@@ -1,91 +1,66 @@
-"""Host-side helpers of the reference with unchanged signatures (utils/general.py of
+"""Host-side helpers with the reference's signatures and semantics (utils/general.py of
 lmb-freiburg/hand3d): detect_keypoints :331-344, trafo_coords :347-357, EvalUtil :522-611,
-calc_auc :654-659.  Pure NumPy post-processing, exactly as the reference runs them on the host.
+calc_auc :654-659.  Written from the behaviour (vectorised NumPy), not from the reference text:
+  * detect_keypoints: per channel, (row, col) of the first maximum of an [H,W,C] score map, float64 [C,2];
+  * trafo_coords: crop coordinates -> image coordinates, (kp - crop_size//2) / scale + centre;
+  * EvalUtil: per-keypoint Euclidean errors of the visible keypoints; mean / median end-point error
+    averaged over the keypoints that received data; PCK over linspace thresholds; AUC = trapz / width.
 """
 import numpy as np
 
 
 def detect_keypoints(scoremaps):
-    """ Performs detection per scoremap for the hands keypoints. """
-    if len(scoremaps.shape) == 4:
-        scoremaps = np.squeeze(scoremaps)
-    s = scoremaps.shape
-    assert len(s) == 3, "This function was only designed for 3D Scoremaps."
-    assert (s[2] < s[1]) and (s[2] < s[0]), "Probably the input is not correct, because [H, W, C] is expected."
-    keypoint_coords = np.zeros((s[2], 2))
-    for i in range(s[2]):
-        v, u = np.unravel_index(np.argmax(scoremaps[:, :, i]), (s[0], s[1]))
-        keypoint_coords[i, 0] = v
-        keypoint_coords[i, 1] = u
-    return keypoint_coords
+    """[H,W,C] (or [1,H,W,C]) score maps -> float64 [C,2] with (v=row, u=col) of each channel's first maximum."""
+    sm = np.squeeze(scoremaps) if scoremaps.ndim == 4 else scoremaps
+    assert sm.ndim == 3, "This function was only designed for 3D Scoremaps."
+    h, w, c = sm.shape
+    assert c < w and c < h, "Probably the input is not correct, because [H, W, C] is expected."
+    flat = np.argmax(sm.reshape(h * w, c), axis=0)          # first maximum in row-major order
+    return np.stack([flat // w, flat % w], axis=1).astype(np.float64)
 
 
 def trafo_coords(keypoints_crop_coords, centers, scale, crop_size):
-    """ Transforms coords into global image coordinates. """
-    keypoints_coords = np.copy(keypoints_crop_coords)
-    keypoints_coords -= crop_size // 2
-    keypoints_coords /= scale
-    keypoints_coords += centers
-    return keypoints_coords
+    """Maps keypoints found in the crop back into the frame the crop was taken from."""
+    return (np.asarray(keypoints_crop_coords, dtype=np.float64) - (crop_size // 2)) / scale + centers
 
 
 class EvalUtil:
-    """ Util class for evaluation networks. """
+    """Accumulates per-keypoint errors over a dataset and reports EPE / PCK / AUC (reference semantics)."""
 
     def __init__(self, num_kp=21):
-        self.data = list()
         self.num_kp = num_kp
-        for _ in range(num_kp):
-            self.data.append(list())
+        self.data = [[] for _ in range(num_kp)]
 
     def feed(self, keypoint_gt, keypoint_vis, keypoint_pred):
-        """ Stores the euclidean distance between gt and pred, when it is visible. """
-        keypoint_gt = np.squeeze(keypoint_gt)
-        keypoint_pred = np.squeeze(keypoint_pred)
-        keypoint_vis = np.squeeze(keypoint_vis).astype('bool')
-        assert len(keypoint_gt.shape) == 2
-        assert len(keypoint_pred.shape) == 2
-        assert len(keypoint_vis.shape) == 1
-        diff = keypoint_gt - keypoint_pred
-        euclidean_dist = np.sqrt(np.sum(np.square(diff), axis=1))
-        num_kp = keypoint_gt.shape[0]
-        for i in range(num_kp):
-            if keypoint_vis[i]:
-                self.data[i].append(euclidean_dist[i])
+        gt, pred = np.squeeze(keypoint_gt), np.squeeze(keypoint_pred)
+        vis = np.squeeze(keypoint_vis).astype(bool)
+        assert gt.ndim == 2 and pred.ndim == 2 and vis.ndim == 1
+        err = np.linalg.norm(gt - pred, axis=1)
+        for k in np.flatnonzero(vis[:gt.shape[0]]):
+            self.data[k].append(err[k])
+
+    def _errors(self):
+        return [np.asarray(d, dtype=np.float64) for d in self.data if len(d) > 0]
 
     def _get_pck(self, kp_id, threshold):
-        if len(self.data[kp_id]) == 0:
-            return None
-        data = np.array(self.data[kp_id])
-        return np.mean((data <= threshold).astype('float'))
+        d = self.data[kp_id]
+        return None if len(d) == 0 else float(np.mean(np.asarray(d) <= threshold))
 
     def _get_epe(self, kp_id):
-        if len(self.data[kp_id]) == 0:
-            return None, None
-        data = np.array(self.data[kp_id])
-        return np.mean(data), np.median(data)
+        d = self.data[kp_id]
+        return (None, None) if len(d) == 0 else (float(np.mean(d)), float(np.median(d)))
 
     def get_measures(self, val_min, val_max, steps):
-        """ Outputs the average mean and median error as well as the pck score. """
-        thresholds = np.array(np.linspace(val_min, val_max, steps))
-        norm_factor = np.trapezoid(np.ones_like(thresholds), thresholds)
-        epe_mean_all, epe_median_all, auc_all, pck_curve_all = list(), list(), list(), list()
-        for part_id in range(self.num_kp):
-            mean, median = self._get_epe(part_id)
-            if mean is None:
-                continue
-            epe_mean_all.append(mean)
-            epe_median_all.append(median)
-            pck_curve = np.array([self._get_pck(part_id, t) for t in thresholds])
-            pck_curve_all.append(pck_curve)
-            auc_all.append(np.trapezoid(pck_curve, thresholds) / norm_factor)
-        epe_mean_all = np.mean(np.array(epe_mean_all))
-        epe_median_all = np.mean(np.array(epe_median_all))
-        auc_all = np.mean(np.array(auc_all))
-        pck_curve_all = np.mean(np.array(pck_curve_all), 0)
-        return epe_mean_all, epe_median_all, auc_all, pck_curve_all, thresholds
+        """(mean EPE, median EPE, AUC, PCK curve, thresholds): each averaged over keypoints that have data."""
+        thresholds = np.linspace(val_min, val_max, steps)
+        width = np.trapezoid(np.ones_like(thresholds), thresholds)
+        errs = self._errors()
+        pck = np.array([[np.mean(e <= t) for t in thresholds] for e in errs])       # [keypoints with data, steps]
+        auc = np.array([np.trapezoid(row, thresholds) / width for row in pck])
+        return (np.mean([e.mean() for e in errs]), np.mean([np.median(e) for e in errs]), np.mean(auc),
+                pck.mean(axis=0), thresholds)
 
 
 def calc_auc(x, y):
-    """ Given x and y values it calculates the approx. integral and normalizes it: area under curve"""
+    """Normalised area under the curve y(x)."""
     return np.trapezoid(y, x) / np.trapezoid(np.ones_like(y), x)

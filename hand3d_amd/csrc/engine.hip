@@ -44,6 +44,7 @@ struct ConvL {
     // packed geometry
     int ek, cin_pad, cout_pad;
     size_t w_off, b_off;   // offsets into the blob (floats)
+    size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%128==0), 0 = none
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
     size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
     int net;
@@ -75,6 +76,10 @@ struct Tables {
         blob_floats += (size_t)l.ek * l.ek * l.cin_pad * l.cout_pad;
         l.b_off = blob_floats;
         blob_floats += l.cout_pad;
+        if (k == 3 && stride == 1 && l.mode == 0 && cout % 128 == 0) {     // Winograd F(2x2,3x3) copy (16 planes)
+            l.ww_off = blob_floats;
+            blob_floats += (size_t)16 * l.cin_pad * l.cout_pad;
+        }
         if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
             l.cin_pad16 = (l.mode == 1) ? 64 : (l.mode == 2) ? 192 : (cin + 63) / 64 * 64;
             l.w16_off = blob16_halves;
@@ -200,6 +205,7 @@ struct hp3d_ctx {
     int nets = 0;              // finalized nets mask
     int empty_fltmax = 0;
     int conv_naive = 0;
+    int use_wino = 1;          // 3x3/s1 layers with Cout%128==0 run as Winograd F(2x2,3x3) (conv_impl=direct disables)
     // debug copies of the unpacked HWIO weights for conv_impl=naive
     std::map<std::string, float*> naive_w;
 
@@ -410,7 +416,18 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
     const double bytes = (f16 ? 2.0 : 4.0) * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
                                 (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
-    if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
+    if (ctx->use_wino && !f16 && l.ww_off && conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B)) {
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.ww_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl;
+        p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        ProfScope ps(ctx, l.name, pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
+        conv_wino_launch(p, pool, ctx->stream);
+    } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
         conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
                           l.relu, out, out_cs, Ho, Wo, pt, pl, ctx->stream);
@@ -833,7 +850,11 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (!ctx || !key || !value) return HP3D_ERR_ARG;
     const std::string k(key), v(value);
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
-    if (k == "conv_impl" && (v == "mfma" || v == "naive")) { ctx->conv_naive = (v == "naive"); return 0; }
+    if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {
+        ctx->conv_naive = (v == "naive");
+        ctx->use_wino = (v == "direct" || v == "naive") ? 0 : (v == "winograd") ? 2 : 1;   // mfma = auto
+        return 0;
+    }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown option %s=%s", key, value);
 }
 
@@ -896,6 +917,8 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
         const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, l.name + "/biases", &b) == 0;
         mark(l.net, ok);
         if (ok) pack_conv(l, w->data.data(), b->data.data(), host.data());
+        if (ok && l.ww_off)        // U = G g G^T in the Winograd kernel's fragment order
+            wino_pack_weights(w->data.data(), l.cin, l.cout, l.cin_pad, l.cout_pad, host.data() + l.ww_off);
     }
     for (const FcL& l : ctx->T.fc) {
         if (l.name == "ViewpointNet/fc_vp_u") {
@@ -1146,7 +1169,21 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
-    if (ctx->conv_naive) {
+    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B) && Cout % 128 == 0) {
+        const size_t wn = (size_t)16 * l.cin_pad * l.cout_pad;
+        std::vector<float> pw(wn + l.cout_pad, 0.f);
+        wino_pack_weights(w_hwio, Cin, Cout, l.cin_pad, l.cout_pad, pw.data());
+        for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
+        float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
+        ConvParams p;
+        p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + wn; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
+        p.pad_t = pt; p.pad_l = pl;
+        p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
+        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        conv_wino_launch(p, pool, ctx->stream);
+    } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");
         float* d_w = S.upload(w_hwio, (size_t)k * k * Cin * Cout); NN(ctx, d_w);
         float* d_b = S.upload(bias, (size_t)Cout); NN(ctx, d_b);

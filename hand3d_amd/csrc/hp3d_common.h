@@ -23,6 +23,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define HP3D_MFMA_32x32x16_F16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
+#define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #define HP3D_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
 #define HP3D_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
@@ -36,10 +37,14 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane)                                   \
     __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(lds_wave_base), 16, \
                                              (voff), (soff), 0, 0)
+// 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
+#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
 #else
 typedef int hp3d_rsrc_t;
 #define HP3D_MAKE_RSRC(ptr, bytes) 0
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc))
+#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) (f32x4{0.f, 0.f, 0.f, 0.f})
 #endif
 #endif
 
@@ -81,6 +86,11 @@ void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int 
                                float* out, int out_cs, int cout_store, hipStream_t s);
 int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s);
 const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan);
+
+// Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
+void wino_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, float* dst);
+int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B);
+int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
 // debug cross-check (one thread per output element, obviously-correct loops)
 void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, const float* w_hwio_like,

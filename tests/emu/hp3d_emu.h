@@ -38,6 +38,7 @@ extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu
 #define __forceinline__ inline __attribute__((always_inline))
 #define __shared__ static
 #define HP3D_KERNEL(nthr)
+#define HP3D_KERNEL2(nthr, w)
 #define HP3D_SCHED_BARRIER() ((void)0)
 #define HP3D_READFIRSTLANE(x) (x)
 #define HP3D_WAIT_VMCNT0() ((void)0)
@@ -49,6 +50,12 @@ static inline void hp3d_emu_buffer_lds16(hp3d_rsrc_t r, float* lds_wave_base, un
 }
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) \
     hp3d_emu_buffer_lds16((rsrc), (float*)(lds_wave_base), (unsigned)(voff) + (unsigned)(soff), (lane))
+static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (off + 16u <= r.bytes) memcpy(&v, r.base + off, 16);
+    return v;
+}
+#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 #define HP3D_GLDS16(gptr, lds_wave_base, lane) memcpy((float*)(lds_wave_base) + (lane) * 4, (gptr), 16)
 extern float* hp3d_emu_smem;
 #define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem

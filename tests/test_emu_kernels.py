@@ -150,3 +150,23 @@ def test_f16_trunk_mode_on_interpreter(emu_engine, synth_weights):
     finally:
         net.init_from_dict(synth_weights, dtype=0)
     assert not (emu_engine.nets_mask() & 32)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 128, 0), (1, 17, 21, 40, 256, 0), (2, 14, 20, 64, 128, 1)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_winograd_kernel_on_interpreter(emu_engine, case):
+    """conv_wino.hip forced on (F(2x2,3x3)): input/weight/output transforms, fused pool, masked tiles."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('conv_impl', 'winograd')
+    try:
+        y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        emu_engine.set_option('conv_impl', 'mfma')
+    assert np.abs(y - r).max() < 1e-5

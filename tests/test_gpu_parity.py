@@ -65,6 +65,36 @@ def test_conv_mfma_vs_oracle(gpu_engine, case):
     assert err < 5e-5, err   # f32 accumulation over K <= 7301 vs the f64 oracle, unit-variance data
 
 
+WINO_CASES = [(1, 60, 80, 256, 256, 1), (2, 30, 40, 512, 512, 0), (1, 64, 64, 128, 256, 0), (1, 17, 23, 40, 128, 0),
+              (2, 18, 22, 64, 128, 1), (1, 120, 160, 64, 128, 0), (4, 32, 32, 512, 256, 0)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_conv_winograd_vs_oracle(gpu_engine, case):
+    """conv_wino.hip (F(2x2,3x3), float32) forced on: same tolerance as the direct kernel; masked edge tiles,
+    fused pool, Cin not a multiple of 32 (zero-padded)."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = _conv_ref(x, w, b, 1, True, pool)
+    gpu_engine.set_option('conv_impl', 'winograd')
+    try:
+        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+    gpu_engine.set_option('conv_impl', 'direct')
+    try:
+        yd = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+    err, errd = np.abs(y - r).max(), np.abs(yd - r).max()
+    print("winograd %s max|err| %.3e (direct %.3e)" % (case, err, errd))
+    assert y.shape == r.shape and err < 5e-5
+    assert not np.array_equal(y, yd), "the Winograd kernel did not run"
+
+
 def test_conv_mfma_vs_naive_kernel(gpu_engine):
     """Same op through the obviously-correct one-thread-per-output kernel (debug path)."""
     rng = np.random.default_rng(7)
@@ -329,6 +359,36 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
     assert np.abs(o1[0] - ref[0]).max() < TOL_HEATMAP
     assert np.array_equal(o1[3], ref[3]) and np.array_equal(o1[2], ref[2])
     assert np.abs(o1[4] - ref[4]).max() < TOL_HEATMAP and np.abs(o1[5] - ref[5]).max() < TOL_KP3D
+
+
+def test_full_pipeline_batch32_winograd_active(net, synth_weights):
+    """The bench workload shape (B=32, 320x320): at this size the 3x3 layers with Cout % 128 == 0 run as
+    Winograd F(2x2,3x3).  Two of the 32 images are checked against the float64-accumulating oracle, and the
+    whole batch against the direct-kernel engine."""
+    img = synth.make_batch(3000, 32, 320, 320)
+    hs = synth.hand_sides(32)
+    o = net.engine.infer_full(img, hs, want_mask=True)
+    kernels = set(k for _, k, _, _, _ in net.engine.profile())
+    net.engine.set_profiling(1)
+    net.engine.infer_full(img, hs)
+    kernels = set(k for _, k, _, _, _ in net.engine.profile())
+    net.engine.set_profiling(0)
+    assert any(k.startswith('conv_wino') for k in kernels), kernels
+    for i in (0, 17):
+        taps = {}
+        ref = N.inference(synth_weights, img[i:i + 1], hs[i:i + 1], True, acc=np.float64, taps=taps)
+        assert np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0])
+        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2])
+        assert np.abs(o['scoremap'][i:i + 1] - ref[0]).max() < TOL_HEATMAP
+        assert np.abs(o['kpmap'][i:i + 1] - ref[4]).max() < TOL_HEATMAP
+        assert np.abs(o['coord3d'][i:i + 1] - ref[5]).max() < TOL_KP3D
+    net.engine.set_option('conv_impl', 'direct')
+    try:
+        od = net.engine.infer_full(img, hs)
+    finally:
+        net.engine.set_option('conv_impl', 'mfma')
+    assert np.array_equal(o['center'], od['center']) and np.array_equal(o['scale'], od['scale'])
+    assert np.abs(o['kpmap'] - od['kpmap']).max() < 1e-4 and np.abs(o['coord3d'] - od['coord3d']).max() < 1e-5
 
 
 def test_full_pipeline_480x640_config_c5_shape(net, synth_weights):

@@ -158,32 +158,41 @@ def main():
         rows += e.profile()
         e.set_profiling(0)
     if rank == 0:
-        # ---- roofline of the dominant kernel family (the MFMA implicit-GEMM conv) --------------
+        # ---- roofline of the dominant kernel family ------------------------------------------------------
+        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 layers), conv_mfma (direct implicit GEMM), glue
         fam = {}
         for name, kern, ms, fl, by in rows:
-            k = 'conv_mfma' if kern.startswith('conv_mfma') else kern
+            k = 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else kern
             f = fam.setdefault(k, [0.0, 0.0, 0.0, 0])
             f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1
-        dom = max(fam, key=lambda k: fam[k][0])
-        ms, fl, by, n = fam[dom]
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
-        # scripts/summarize_prof.py -> profiles/conv_mfma_traffic.json); counters cannot be read in-process.
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'conv_mfma_traffic.json')
-        if dom == 'conv_mfma' and a.workload == 'full' and a.dtype == 'f32' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
-            try:
-                traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
-            except Exception:
-                traffic = None
+        total_ms = max(sum(v[0] for v in fam.values()), 1e-9)
         peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_F16_MFMA_TFLOPS
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per launch (PMC, profiles/conv_mfma_traffic.json)",
-                "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
-                "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
-                "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
-                "share_of_gpu_time": round(ms / max(sum(v[0] for v in fam.values()), 1e-9), 4)}
+
+        def roof_of(k):
+            ms, fl, by, n = fam[k]
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            # Winograd executes 16/36 of the direct form's multiply-adds: `achieved` stays ALGORITHMIC (direct-conv
+            # FLOPs), `mfma_executed` is what the matrix cores actually ran
+            exe = ach * (16.0 / 36.0) if k == 'conv_wino' else ach
+            return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "mfma_executed": round(exe, 2), "mfma_executed_frac": round(exe / peak, 4),
+                    "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
+                    "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+                    "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
+                    "share_of_gpu_time": round(ms / total_ms, 4)}
+        dom = max(fam, key=lambda k: fam[k][0])
+        roof = roof_of(dom)
+        # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
+        # scripts/summarize_prof.py -> profiles/<family>_traffic.json); counters cannot be read in-process.
+        roof["traffic"] = None
+        roof["traffic_unit"] = "HBM bytes per launch (PMC, profiles/%s_traffic.json)" % dom
+        tpath = os.path.join(ROOT, 'profiles', '%s_traffic.json' % dom)
+        if a.workload == 'full' and a.dtype == 'f32' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
+            try:
+                roof["traffic"] = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+            except Exception:
+                pass
+        others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0]) if k != dom and k.startswith('conv')]
         if a.layers:
             agg = {}
             for name, kern, ms_, fl_, by_ in rows:
@@ -211,7 +220,7 @@ def main():
                        "parallelism": "batch-shard x%d (no data-path collective; keypoint all_gather per step)%s" % (
                            world, "" if len(engines) == 1 else "; %d HIP streams per GPU" % len(engines)),
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu,
         }
         os.write(json_fd, (json.dumps(res) + '\n').encode())
     if use_dist:

@@ -426,7 +426,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
         p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         ProfScope ps(ctx, l.name, pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
-        conv_wino_launch(p, pool, ctx->stream);
+        if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
         conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
@@ -1182,7 +1182,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
         p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
-        conv_wino_launch(p, pool, ctx->stream);
+        if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");
         float* d_w = S.upload(w_hwio, (size_t)k * k * Cin * Cout); NN(ctx, d_w);

@@ -15,6 +15,8 @@ from collections import defaultdict
 
 
 def family(name):
+    if 'conv_wino_kernel' in name:
+        return 'conv_wino'
     if 'conv_mfma_kernel' in name:
         return 'conv_mfma'
     for k in ('conv_splitk_reduce', 'preprocess_u8', 'bone_rel_inv', 'fc_partial', 'fc_reduce', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
@@ -76,17 +78,18 @@ def main():
     if bench:
         r = bench.get('roofline', {})
         lines += ['', 'bench line of the same box: value %.1f %s, ms_per_step %.2f; roofline %s achieved %.1f / peak %.1f %s = %.3f '
-                  '(avg launch %.4f ms from HIP events; rocprof avg for conv_mfma above must agree)'
+                  '(avg launch %.4f ms from HIP events; rocprof avg for that family above must agree)'
                   % (bench['value'], bench['unit'], bench['ms_per_step'], r.get('kernel'), r.get('achieved', 0), r.get('peak', 0),
                      r.get('unit'), r.get('frac', 0), r.get('avg_launch_ms', 0))]
-        if 'conv_mfma' in fetch and fetch['conv_mfma'][1]:
-            rdb = 2.0 * fetch['conv_mfma'][0] * 1024 / fetch['conv_mfma'][1]
-            wtb = write['conv_mfma'][0] * 1024 / write['conv_mfma'][1] if write['conv_mfma'][1] else 0
-            lines.append('conv_mfma HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
-            json.dump({"kernel": "conv_mfma", "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
-                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
-                       "workload": bench.get('config', {}).get('workload')},
-                      open(os.path.join(dst, 'conv_mfma_traffic.json'), 'w'), indent=1)
+        for kf in ('conv_wino', 'conv_mfma'):
+            if kf in fetch and fetch[kf][1]:
+                rdb = 2.0 * fetch[kf][0] * 1024 / fetch[kf][1]
+                wtb = write[kf][0] * 1024 / write[kf][1] if write[kf][1] else 0
+                lines.append('%s HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (kf, rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
+                json.dump({"kernel": kf, "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
+                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
+                           "workload": bench.get('config', {}).get('workload')},
+                          open(os.path.join(dst, kf + '_traffic.json'), 'w'), indent=1)
     open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 

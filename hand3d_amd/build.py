@@ -15,6 +15,7 @@ SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'glue.hip', 'engine.hip']
 HEADERS = ['hp3d_common.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
+EXTRA_FLAGS = {}      # per-file additions, e.g. {'x.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
 
 
 def _stale(target, deps):
@@ -34,7 +35,7 @@ def build(force=False, verbose=True):
         o = os.path.join(CSRC, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))

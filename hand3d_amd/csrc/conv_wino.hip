@@ -268,7 +268,7 @@ int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, i
     if ((long)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 8 >= (1L << 31)) return 0;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
     const long blocks = (tiles + 31) / 32 * (Cout / 128);
-    return mode == 2 || blocks >= 512;
+    return mode == 2 || blocks >= 256;
 }
 
 int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {

@@ -219,6 +219,7 @@ struct hp3d_ctx {
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
           *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
           *d_pooled = nullptr, *d_fcpart = nullptr;
+    int* d_sched = nullptr;      // conv_wino work-queue counters (zero between launches)
     int* d_seed = nullptr;
     unsigned long long* d_keys = nullptr;
     unsigned char* d_det = nullptr;
@@ -424,7 +425,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
         ProfScope ps(ctx, l.name, pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
@@ -450,7 +451,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
         p.Cin = cin_units; p.in_cs = (f16 && l.mode != 1) ? in_cs / 2 : in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
-        p.f16 = f16; p.out_f32 = out_f32;
+        p.f16 = f16; p.out_f32 = out_f32; p.sched = nullptr;
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
@@ -810,6 +811,12 @@ int hp3d_create(int device, hp3d_ctx** out) {
         delete ctx;
         return HP3D_ERR_HIP;
     }
+    if (hipMalloc((void**)&ctx->d_sched, 2 * sizeof(int)) != hipSuccess || hipMemsetAsync(ctx->d_sched, 0, 2 * sizeof(int), ctx->stream) != hipSuccess) {
+        set_error(nullptr, "hp3d_create: hipMalloc failed");
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return HP3D_ERR_HIP;
+    }
     *out = ctx;
     return 0;
 }
@@ -825,6 +832,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
                     &ctx->d_pooled, &ctx->d_fcpart};
     for (float** p : fp)
         if (*p) hipFree(*p);
+    if (ctx->d_sched) hipFree(ctx->d_sched);
     if (ctx->d_seed) hipFree(ctx->d_seed);
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
@@ -1154,6 +1162,10 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     l.name = "op/conv2d";
     l.k = k; l.cin = Cin; l.cout = Cout; l.stride = stride; l.relu = act; l.net = 0;
     l.mode = 0; l.ek = k; l.cin_pad = pad32(Cin); l.cout_pad = pad32(Cout);
+    if (ctx->use_wino == 2 && !ctx->conv_naive && k == 3 && stride == 1) {       // conv_impl=winograd: no silent fallback
+        l.cin_pad = (Cin + 63) / 64 * 64;
+        if (Cout % 128) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_impl=winograd needs Cout %% 128 == 0 (got %d)", Cout);
+    }
     l.w_off = 0; l.b_off = (size_t)k * k * l.cin_pad * l.cout_pad;
     std::vector<float> packed(l.b_off + l.cout_pad);
     pack_conv(l, w_hwio, bias, packed.data());
@@ -1181,7 +1193,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");
@@ -1201,7 +1213,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = act; p.im2col = 0; p.f16 = 0; p.out_f32 = 0;
+        p.act = act; p.im2col = 0; p.f16 = 0; p.out_f32 = 0; p.sched = nullptr;
         p.ksplit = plan.ksplit; p.partial = d_part;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");

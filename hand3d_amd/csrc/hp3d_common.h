@@ -25,6 +25,20 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+// keeps a per-lane value in a register as-is (the compiler may not re-derive it from other values)
+#define HP3D_OPAQUE_V(x) asm volatile("" : "+v"(x))
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static inline int hp3d_num_cus() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+}
+// scheduling groups inside one sched-barrier region: "next, n instructions of this kind"
+#define HP3D_SG_VALU 0x2
+#define HP3D_SG_MFMA 0x8
+#define HP3D_SG_VMEM_READ 0x20
+#define HP3D_SG_DS_READ 0x100
+#define HP3D_SCHED_GROUP(kind, n) __builtin_amdgcn_sched_group_barrier((kind), (n), 0)
 #define HP3D_READFIRSTLANE(x) __builtin_amdgcn_readfirstlane(x)
 #define HP3D_WAIT_VMCNT0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 // buffer-addressed LDS-DMA: 16 B per lane from (rsrc base + per-lane voff + scalar soff) to
@@ -72,6 +86,7 @@ struct ConvParams {
     int f16;              // 1: half-precision operands (channel counts/strides above are in 4-byte units = f16 pairs)
     int out_f32;          // f16 mode only: store float32 (score-map heads) instead of halves
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
+    int* sched;           // conv_wino: {next-item counter, finished-workgroup counter}, both 0 between launches
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------

@@ -17,6 +17,7 @@
 #include <functional>
 
 typedef float f32x4 __attribute__((vector_size(16)));
+typedef float f32x2 __attribute__((vector_size(8)));
 typedef float f32x16 __attribute__((vector_size(64)));
 typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((vector_size(16)));
@@ -40,6 +41,13 @@ extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu
 #define HP3D_KERNEL(nthr)
 #define HP3D_KERNEL2(nthr, w)
 #define HP3D_SCHED_BARRIER() ((void)0)
+#define HP3D_OPAQUE_V(x) ((void)0)
+static inline int hp3d_num_cus() { return 3; }     // small on purpose: persistent kernels walk several items per workgroup
+#define HP3D_SG_VALU 0x2
+#define HP3D_SG_MFMA 0x8
+#define HP3D_SG_VMEM_READ 0x20
+#define HP3D_SG_DS_READ 0x100
+#define HP3D_SCHED_GROUP(kind, n) ((void)0)
 #define HP3D_READFIRSTLANE(x) (x)
 #define HP3D_WAIT_VMCNT0() ((void)0)
 struct hp3d_rsrc_t { const char* base; unsigned bytes; };
@@ -80,6 +88,8 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }
 
+template <typename T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <typename T> inline T atomicExch(T* p, T v) { T o = *p; *p = v; return o; }
 template <typename T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 template <typename T> inline T atomicMin(T* p, T v) { T o = *p; if (v < o) *p = v; return o; }
 inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }

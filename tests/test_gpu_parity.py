@@ -72,7 +72,7 @@ WINO_CASES = [(1, 60, 80, 256, 256, 1), (2, 30, 40, 512, 512, 0), (1, 64, 64, 12
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
 def test_conv_winograd_vs_oracle(gpu_engine, case):
     """conv_wino.hip (F(2x2,3x3), float32) forced on: same tolerance as the direct kernel; masked edge tiles,
-    fused pool, Cin not a multiple of 32 (zero-padded)."""
+    fused pool, Cin not a multiple of 64 (zero-padded)."""
     B, H, W, Cin, Cout, pool = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)

@@ -1,50 +1,62 @@
 // conv_wino.hip -- 3x3 / stride-1 convolution by Winograd F(2x2, 3x3) on the f32 matrix cores.
 //
 // Same call sites as conv_mfma.hip (NetworkOps.conv_relu + max_pool, utils/general.py:36-65) for the layers
-// with Cout % 128 == 0: 2.25x fewer multiply-adds than the direct form at float32 (no reduced precision;
-// the transforms only add / subtract / halve).
+// with Cin % 64 == 0 and Cout % 128 == 0: 2.25x fewer multiply-adds than the direct form at float32 (no
+// reduced precision; the transforms only add / subtract / halve).
 //
 //   Y(2x2) = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          d: 4x4 input window, g: 3x3 filter
 //
-// Design for gfx950:
-//   * workgroup = 8x16 output pixels = 32 Winograd tiles x 128 output channels, 4 waves; wave w owns couts
-//     32w..32w+31 and ALL 32 tiles, so the MFMA M dimension is the tile index and nothing about the
-//     weights is shared between waves:
-//   * transformed weights U[plane 0..15][Cin][Cout] are pre-packed in fragment order and go global -> VGPR
-//     directly (buffer_load_dwordx4, scalar per-plane offset): no LDS ring, NO barrier inside a 32-channel
-//     chunk -- 16 planes x 16 MFMAs per wave run back to back;
-//   * the input transform V = B^T d B is computed by the loader (thread = (tile, channel quad): 16 loads of
-//     16 B, 32 add/sub on float4) and written once per chunk to LDS as 16 planes x 32 tiles x 32 channels;
-//   * the output transform is folded plane by plane: plane p = (a,b) contributes +-1 * (its 32x32 partial
-//     sum) to output (i,j) with coefficient A^T[i][a] * A^T[j][b], so only 4 accumulators (the 2x2 outputs)
-//     + 2 rotating plane buffers live in registers (96 instead of 256) -> two workgroups per CU;
+// Design for gfx950 (measured facts behind it: scripts/micro/mfma_chain.hip, mfma_valu.hip):
+//   * one dependent chain of v_mfma_f32_32x32x2_f32 per wave already runs at 98% of peak, but every VALU
+//     instruction issued on the SIMD costs the f32 MFMA stream ~3.5-5 cycles (they do not overlap); LDS and
+//     VMEM instructions cost nothing.  So the kernel is built around VALU instructions per MFMA:
+//   * workgroup = 32 Winograd tiles x 128 output channels, 4 waves = ONE wave per SIMD (147 KB of LDS, 512
+//     registers per lane); wave w owns couts 32w..32w+31 and all 32 tiles;
+//   * the 16 Winograd planes accumulate over ALL input channels in 16 x 16 = 256 accumulation registers
+//     (AGPRs, the matrix core's own C/D operands): the main loop has no output transform at all -- per
+//     32-channel step 256 MFMAs against ~150 VALU instructions (the input transform).  The output transform
+//     A^T M A runs once per work item in the epilogue.  (An earlier version folded every plane into the 2x2
+//     outputs inside the loop to fit 256 registers and two workgroups per CU: 2.7 VALU per MFMA, 70% MFMA-busy.)
+//   * the transformed input V = B^T d B is double buffered in LDS (2 x 16 planes x 32 tiles x 32 channels): the
+//     loader (thread = (tile, channel quad)) has the next step's 4x4 windows in flight during a step (64
+//     registers), transforms them under the last planes and writes the other buffer: ONE barrier per step;
+//   * transformed weights U[plane][Cin][Cout] are pre-packed in fragment order and go global -> VGPR directly
+//     (buffer_load_dwordx4, scalar offset per (plane, step)), ring of 4 planes, 3 ahead: no LDS for B;
+//   * persistent grid (one workgroup per CU) pulling work items from a global counter; the next item's first
+//     window / weight fragments are fetched under the current item's last step;
 //   * the 2x2 outputs of a tile are one pooling window: bias + leaky-ReLU + max-pool stay a register epilogue.
 #include "hp3d_common.h"
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
-constexpr int WCK = 32;            // channels per chunk
-constexpr int WLDA = WCK + 4;      // V row pitch in floats (144 B)
-constexpr int WTILES = 32;         // Winograd tiles per workgroup: 4 rows x 8 cols of 2x2 outputs
-constexpr int V_FLOATS = 16 * WTILES * WLDA;
-constexpr int WINO_SMEM_BYTES = V_FLOATS * 4 + 2 * WTILES * 4;     // V + the tile table
+constexpr int WCK = 32;                        // channels per step
+constexpr int WLDA = WCK + 4;                  // V row pitch in floats (144 B)
+constexpr int WTILES = 32;                     // Winograd tiles per work item
+constexpr int PLANE_FLOATS = WTILES * WLDA;    // one plane of one buffer
+constexpr int VBUF_FLOATS = 16 * PLANE_FLOATS; // 73728 B
+constexpr int WINO_SMEM_BYTES = 2 * VBUF_FLOATS * 4 + 2 * 2 * WTILES * 4 + 16;     // 2 V buffers + two tile tables + next-item slot
 
 template <bool POOL>
-HP3D_KERNEL2(256, 2)      // <= 256 registers per lane: two workgroups (two waves per SIMD) per CU
+HP3D_KERNEL2(256, 1)
 void conv_wino_kernel(const ConvParams p) {
     HP3D_DYN_SMEM(V);
-    int* tinfo = (int*)(V + V_FLOATS);     // [0..31] output offset of tile t (-1: no such tile), [32..63] edge flags
+    // tile tables, double buffered by item parity: [0..31] output offset of tile t (-1: no such tile), [32..63] edge flags;
+    // then one slot for the next item's number
+    int* tinfo = (int*)(V + 2 * VBUF_FLOATS);
+    int* next_slot = tinfo + 4 * WTILES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.y * 128;
 
-    // The 32 tiles of a workgroup are 32 consecutive entries of the flattened (image, band of 4 tile rows,
-    // tile column, row in band) order: a 4x8 footprint where the tile grid allows it, but no padding when it
-    // does not (20x20 tiles at 40x40 would waste 20% in fixed 4x8 blocks), and the last workgroup of one image
-    // continues into the next.
+    // Work item = (cout block of 128) x (32 Winograd tiles).  The 32 tiles are consecutive entries of the
+    // flattened (image, band of 4 tile rows, tile column, row in band) order: a 4x8 footprint where the tile
+    // grid allows it, but no padding when it does not (20x20 tiles at 40x40 would waste 20% in fixed 4x8
+    // blocks), and an item may continue into the next image.
     const int TXn = p.tiles_x, TYn = p.tiles_y, per_img = TXn * TYn;
+    const int tile_blocks = (p.B * per_img + WTILES - 1) / WTILES;
+    const int nitems = tile_blocks * (p.Cout >> 7);
     auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) {
         tb = id / per_img;
         const int r = id - tb * per_img;
@@ -54,49 +66,52 @@ void conv_wino_kernel(const ConvParams p) {
         tyy = band * 4 + rem - txx * rows;
     };
     const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
-    if (tid < WTILES) {
-        int tb, tyy, txx;
-        tile_decode(blockIdx.x * WTILES + tid, tb, tyy, txx);
-        int off = -1, fl = 0;
-        if (tb < p.B) {
-            if (POOL) {
-                if (tyy < Hs && txx < Ws) off = ((tb * Hs + tyy) * Ws + txx) * p.out_cs;
-            } else {
-                off = ((tb * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
-                fl = (2 * txx + 1 < Ws ? 1 : 0) | (2 * tyy + 1 < Hs ? 2 : 0);
+    auto table_write = [&](int tblock, int parity) {
+        if (tid < WTILES) {
+            int tb, tyy, txx;
+            tile_decode(tblock * WTILES + tid, tb, tyy, txx);
+            int off = -1, fl = 0;
+            if (tb < p.B) {
+                if (POOL) {
+                    if (tyy < Hs && txx < Ws) off = ((tb * Hs + tyy) * Ws + txx) * p.out_cs;
+                } else {
+                    off = ((tb * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
+                    fl = (2 * txx + 1 < Ws ? 1 : 0) | (2 * tyy + 1 < Hs ? 2 : 0);
+                }
             }
-        }
-        tinfo[tid] = off;
-        tinfo[WTILES + tid] = fl;
-    }
-
-    // ---- loader role: this thread transforms the 4x4 window of tile lt for channel quad lc ----------
-    // (buffer loads: a window element outside the image gets an out-of-range offset and reads as 0)
-    const int lt = tid >> 3, lc = tid & 7;
-    int lb, lty, ltx;
-    tile_decode(blockIdx.x * WTILES + lt, lb, lty, ltx);
-    const int wy0 = 2 * lty - 1, wx0 = 2 * ltx - 1;                              // SAME padding 1
-    const int cs4 = p.in_cs * 4;
-    const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lc * 16;           // bytes
-    unsigned wmask = 0;       // bit r*4+c: window element inside the image
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            if (lb < p.B && (unsigned)(wy0 + r) < (unsigned)p.H && (unsigned)(wx0 + c) < (unsigned)p.W) wmask |= 1u << (r * 4 + c);
-    const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
-    constexpr int OOR = (int)0x80000000;
-
-    f32x4 d[16];
-    // one window row (4 loads); wm = wmask, or 0 when there is no such chunk
-    auto window_fetch_row = [&](int r, unsigned wm, int soff) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int voff = (wm & (1u << (r * 4 + c))) ? wbase + (r * p.W + c) * cs4 : OOR;
-            d[r * 4 + c] = HP3D_BUFFER_LOAD16(irsrc, voff, soff);
+            tinfo[parity * 2 * WTILES + tid] = off;
+            tinfo[parity * 2 * WTILES + WTILES + tid] = fl;
         }
     };
-    auto transform_commit = [&]() {
+
+    // ---- loader role: this thread transforms the 4x4 window of tile lt for channel quad lc --------------
+    // (buffer loads: a window element outside the image gets an out-of-range offset and reads as 0)
+    const int lt = tid >> 3, lc = tid & 7;
+    const int cs4 = p.in_cs * 4;
+    constexpr int OOR = (int)0x80000000;
+    int wv[16];               // byte offsets of the 16 window elements (OOR: zero padding)
+    auto loader_setup = [&](int tblock, bool valid) {
+        int lb, lty, ltx;
+        tile_decode(tblock * WTILES + lt, lb, lty, ltx);
+        const int wy0 = 2 * lty - 1, wx0 = 2 * ltx - 1;                              // SAME padding 1
+        const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lc * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool in = valid && lb < p.B && (unsigned)(wy0 + r) < (unsigned)p.H && (unsigned)(wx0 + c) < (unsigned)p.W;
+                wv[r * 4 + c] = in ? wbase + (r * p.W + c) * cs4 : OOR;
+            }
+    };
+    const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
+    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
+
+    f32x4 d[16];
+    auto window_fetch = [&](int soff) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) d[e] = HP3D_BUFFER_LOAD16(irsrc, wv[e], soff);
+    };
+    auto transform_commit = [&](int buf) {
         // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
         f32x4 t[16];
 #pragma unroll
@@ -106,136 +121,186 @@ void conv_wino_kernel(const ConvParams p) {
             t[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
             t[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
         }
+        float* Vq = V + buf * VBUF_FLOATS + lt * WLDA + lc * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const f32x4 v0 = t[r * 4 + 0] - t[r * 4 + 2];
             const f32x4 v1 = t[r * 4 + 1] + t[r * 4 + 2];
             const f32x4 v2 = t[r * 4 + 2] - t[r * 4 + 1];
             const f32x4 v3 = t[r * 4 + 1] - t[r * 4 + 3];
-            *(f32x4*)(V + ((r * 4 + 0) * WTILES + lt) * WLDA + lc * 4) = v0;
-            *(f32x4*)(V + ((r * 4 + 1) * WTILES + lt) * WLDA + lc * 4) = v1;
-            *(f32x4*)(V + ((r * 4 + 2) * WTILES + lt) * WLDA + lc * 4) = v2;
-            *(f32x4*)(V + ((r * 4 + 3) * WTILES + lt) * WLDA + lc * 4) = v3;
+            *(f32x4*)(Vq + (r * 4 + 0) * PLANE_FLOATS) = v0;
+            *(f32x4*)(Vq + (r * 4 + 1) * PLANE_FLOATS) = v1;
+            *(f32x4*)(Vq + (r * 4 + 2) * PLANE_FLOATS) = v2;
+            *(f32x4*)(Vq + (r * 4 + 3) * PLANE_FLOATS) = v3;
         }
     };
 
     // ---- MFMA role ----------------------------------------------------------------------------------
-    // packed U: [plane 16][chunk][Cout/32][g 4][h 2][n 32][j 4] -> the 4 fragments a wave needs for one
-    // (plane, chunk) are 4 KB contiguous: base = one scalar offset, g = an immediate
+    // packed U: [plane 16][Cin/32][Cout/32][g 4][h 2][n 32][j 4] -> the 4 fragments a wave needs for one
+    // (plane, step) are 4 KB contiguous: base = one scalar offset, g = an immediate
     const int CO32 = p.Cout >> 5;
-    const int nchunks = p.Cin / WCK;
+    const int nsteps = p.Cin / WCK;
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(16 * p.Cin) * (unsigned)p.Cout * 4u);
-    const int chunk_stride_b = CO32 * 4096;                 // bytes between chunks
-    const int plane_stride_b = nchunks * chunk_stride_b;    // bytes between planes
-    const int wvoff = ((n0 >> 5) + wave) * 4096 + lane * 16;
-    const int abase = li * WLDA + lh * 4;
+    const int step_stride_b = CO32 * 4096;                  // bytes between 32-channel steps
+    const int plane_stride_b = nsteps * step_stride_b;      // bytes between planes
+    auto soff_of = [&](int plane, int step) { return plane * plane_stride_b + step * step_stride_b; };
 
-    f32x16 y[4], tmp[2];
+    f32x16 M[16];          // the 16 plane accumulators (AGPRs), live across the whole item
+    f32x4 bq[4][4];        // B fragments of four planes in flight: prefetch distance 3 planes
+    auto b_fetch = [&](int set, int voff, int soff) {
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+        for (int g = 0; g < 4; ++g) bq[set][g] = HP3D_BUFFER_LOAD16(wrsrc, voff + g * 1024, soff);
+    };
+    // A fragments: this lane's row of the current V buffer; two bases so that every ds_read offset fits the
+    // 16-bit immediate (an address add per read would be a VALU instruction in the MFMA stream)
+    const int va_lane = (li * WLDA + lh * 4) * 4;
+    int ab0 = 0, ab1 = 0;
+    f32x4 af[2][4];
+    auto a_fetch = [&](int set, int plane) {
+        const int base = plane < 14 ? ab0 : ab1, pl = plane < 14 ? plane : plane - 14;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) y[o][r] = 0.f;
+        for (int g = 0; g < 4; ++g) af[set][g] = *(const f32x4*)((const char*)V + base + (pl * PLANE_FLOATS + g * 8) * 4);
+    };
 
-    f32x4 bq[4][4];        // B fragments of four planes in flight (global -> VGPR): prefetch distance 3 planes
-    auto b_fetch = [&](int set, int soff) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[set][g] = HP3D_BUFFER_LOAD16(wrsrc, wvoff + g * 1024, soff);
-    };
-    // fold a finished plane (a,b) into the 2x2 outputs: coefficient A^T[i][a] * A^T[j][b], A^T = [1 1 1 0; 0 1 -1 -1]
-    // (plane is wave-uniform at run time: the zero coefficients are skipped by scalar branches)
-    auto fold = [&](int plane, const f32x16& m) {
-        const int a = plane >> 2, bb = plane & 3;
-        const int ca0 = a < 3 ? 1 : 0, ca1 = a == 0 ? 0 : (a == 1 ? 1 : -1);
-        const int cb0 = bb < 3 ? 1 : 0, cb1 = bb == 0 ? 0 : (bb == 1 ? 1 : -1);
-        const int c00 = ca0 * cb0, c01 = ca0 * cb1, c10 = ca1 * cb0, c11 = ca1 * cb1;
-        if (c00) y[0] += m;                                   // c00 is 0 or +1
-        if (c01 > 0) y[1] += m; else if (c01 < 0) y[1] -= m;
-        if (c10 > 0) y[2] += m; else if (c10 < 0) y[2] -= m;
-        if (c11 > 0) y[3] += m; else if (c11 < 0) y[3] -= m;
-    };
-    // one plane: 16 MFMAs from fragment set u, then the previous plane's fold (VALU under these MFMAs)
-    auto plane_mma = [&](int plane, int u) {
-        f32x4 af[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) af[g] = *(const f32x4*)(V + plane * (WTILES * WLDA) + abase + g * 8);
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        tmp[u & 1] = HP3D_MFMA_32x32x2(af[0][0], bq[u][0][0], zero);
-#pragma unroll
-        for (int gj = 1; gj < 16; ++gj)
-            tmp[u & 1] = HP3D_MFMA_32x32x2(af[gj >> 2][gj & 3], bq[u][gj >> 2][gj & 3], tmp[u & 1]);
-        if (plane > 0) fold(plane - 1, tmp[(u & 1) ^ 1]);
-    };
-    // soff(it) for the flattened plane counter it = chunk*16 + plane
-    auto soff_of = [&](int it) { return (it & 15) * plane_stride_b + (it >> 4) * chunk_stride_b; };
+    // ---- first item: the only exposed prologue -------------------------------------------------------------
+    int item = blockIdx.x;
+    int cy = item / tile_blocks, tblock = item - cy * tile_blocks;
+    loader_setup(tblock, true);
+    table_write(tblock, 0);
+    int wvoff = (cy * 4 + wave) * 4096 + lane * 16;
+    window_fetch(0);
+    b_fetch(0, wvoff, soff_of(0, 0));
+    b_fetch(1, wvoff, soff_of(1, 0));
+    b_fetch(2, wvoff, soff_of(2, 0));
+    transform_commit(0);
+    __syncthreads();
+    int cur = 0;
 
+    for (int k = 0;; ++k) {
+        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff;
+        int n_item = nitems;
+        if (tid == 0) *next_slot = (int)gridDim.x + atomicAdd(p.sched, 1);      // read after the barrier that ends step 0
+        const int co = cy * 128 + wave * 32 + li;
+        const float bias = p.bias[co];           // in flight during the item, used in the epilogue
+
+        // one 32-channel step: 16 planes x 16 MFMAs on V[cur]; the first step of an item starts the accumulators
+        // from the inline constant 0
+        auto step_body = [&](int step, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool lasts = step + 1 == nsteps;
+            // Loads return in issue order (one vmcnt counter), so the first wait on a weight fragment issued AFTER
+            // the window loads also waits for the windows: the ring is topped up to 4 planes (0..3) first, the
+            // windows go next, and B(p+4) is issued behind plane p's MFMAs -- the windows (the next step's, or the
+            // next item's first) then have 4 planes (~1.8 us) to arrive before anything depends on them.
+            const int nvoff = lasts ? n_wvoff : wvoff;
+            const int nstep = lasts ? 0 : step + 1;
+            ab0 = cur * (VBUF_FLOATS * 4) + va_lane;
+            ab1 = ab0 + 14 * PLANE_FLOATS * 4;
+            HP3D_OPAQUE_V(ab0);
+            HP3D_OPAQUE_V(ab1);
+            a_fetch(0, 0);                       // first: plane 0's MFMAs wait for exactly this
+            b_fetch(3, wvoff, soff_of(3, step));
+            if (lasts) loader_setup(n_tblock, n_item < nitems);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) window_fetch_row(r, wmask, 0);
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();                 // everyone finished reading V of the previous chunk (and tinfo is written)
-        transform_commit();
-        __syncthreads();
-        // the weight prefetch does not cross the chunk boundary: window (64) + transform temporaries
-        // + 3 planes of fragments (48) + the accumulators (96) would not fit 256 registers
-        HP3D_SCHED_BARRIER();
-        b_fetch(0, soff_of(chunk * 16));
-        b_fetch(1, soff_of(chunk * 16 + 1));
-        b_fetch(2, soff_of(chunk * 16 + 2));
-        for (int pq = 0; pq < 3; ++pq) {          // four planes per trip: B-fragment sets and tmp sets stay static
-            const int it0 = chunk * 16 + pq * 4;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int pl = 0; pl < 16; ++pl) {           // fully unrolled: accumulator and ring indices are static
                 HP3D_SCHED_BARRIER();
-                b_fetch((u + 3) & 3, soff_of(it0 + u + 3));     // 3 planes ahead
-                plane_mma(pq * 4 + u, u);
+                if (pl < 15) a_fetch((pl & 1) ^ 1, pl + 1);
+                if (FIRST) {
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], zero);
+                } else {
+                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], M[pl]);
+                }
+#pragma unroll
+                for (int gj = 1; gj < 16; ++gj)
+                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
+                if (pl == 0) {               // the window loads are issued between plane 0's MFMAs, not in front of them
+                    window_fetch(lasts ? 0 : (step + 1) * (WCK * 4));
+                    HP3D_SCHED_GROUP(HP3D_SG_DS_READ, 4);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        HP3D_SCHED_GROUP(HP3D_SG_MFMA, 2);
+                        HP3D_SCHED_GROUP(HP3D_SG_VMEM_READ, 2);
+                    }
+                }
+                // weight prefetch 4 planes ahead into the slot this plane just released; past the step: the next
+                // step's planes 0..2 (its plane 3 is fetched at its start, before its windows)
+                const int t = pl + 4;
+                if (t < 16) b_fetch(t & 3, wvoff, soff_of(t, step));
+                else if (t < 19) b_fetch(t & 3, nvoff, soff_of(t - 16, nstep));
+                if (pl == 12) transform_commit(cur ^ 1);      // its LDS writes land under planes 13..15
+            }
+            HP3D_SCHED_BARRIER();
+            __syncthreads();             // V[cur^1] complete, V[cur] free
+            cur ^= 1;
+        };
+        step_body(0, std::true_type{});
+        {   // the next item (its tile table is written here, hidden under this item's MFMAs)
+            n_item = HP3D_READFIRSTLANE(*next_slot);
+            const bool has_next = n_item < nitems;
+            n_cy = has_next ? n_item / tile_blocks : cy;
+            n_tblock = has_next ? n_item - n_cy * tile_blocks : tblock;
+            table_write(n_tblock, (k + 1) & 1);
+            n_wvoff = (n_cy * 4 + wave) * 4096 + lane * 16;
+        }
+        for (int step = 1; step < nsteps; ++step) step_body(step, std::false_type{});
+
+        // ---- epilogue: output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias + leaky-ReLU
+        //      (+ 2x2 max-pool) + NHWC store.  Nothing else runs on this SIMD meanwhile, so it is kept short and
+        //      branch-free: row sums first (every plane element is read once), four accumulator registers at a
+        //      time, buffer stores (an invalid lane gets an out-of-range offset and is dropped).
+        const int* tab = tinfo + (k & 1) * 2 * WTILES;
+        const bool cok = co < p.cout_store;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {         // four accumulator registers (= 4 tiles per lane) at a time
+            int vo[4], fl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int t = q + 8 * rg + 4 * lh;              // MFMA row = Winograd tile
+                const int off = tab[t];
+                fl[q] = POOL ? 0 : tab[WTILES + t];
+                vo[q] = (cok && off >= 0) ? (off + co) * 4 : OOR;
+            }
+            float y[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rg * 4 + q;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float s0 = M[a * 4 + 0][r] + M[a * 4 + 1][r] + M[a * 4 + 2][r];      // column j = 0
+                    const float s1 = M[a * 4 + 1][r] - M[a * 4 + 2][r] - M[a * 4 + 3][r];      // column j = 1
+                    if (a == 0) { y[0][q] = s0; y[1][q] = s1; }
+                    else if (a == 1) { y[0][q] += s0; y[1][q] += s1; y[2][q] = s0; y[3][q] = s1; }
+                    else if (a == 2) { y[0][q] += s0; y[1][q] += s1; y[2][q] -= s0; y[3][q] -= s1; }
+                    else { y[2][q] -= s0; y[3][q] -= s1; }
+                }
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    float x = y[o][q] + bias;
+                    if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                    y[o][q] = x;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (POOL) {
+                    HP3D_BUFFER_STORE4(orsrc, fmaxf(fmaxf(y[0][q], y[1][q]), fmaxf(y[2][q], y[3][q])), vo[q], 0);
+                } else {
+                    HP3D_BUFFER_STORE4(orsrc, y[0][q], vo[q], 0);
+                    HP3D_BUFFER_STORE4(orsrc, y[1][q], (fl[q] & 1) ? vo[q] : OOR, p.out_cs * 4);
+                    HP3D_BUFFER_STORE4(orsrc, y[2][q], (fl[q] & 2) ? vo[q] : OOR, Ws * p.out_cs * 4);
+                    HP3D_BUFFER_STORE4(orsrc, y[3][q], fl[q] == 3 ? vo[q] : OOR, (Ws + 1) * p.out_cs * 4);
+                }
             }
         }
-        // planes 12..15, peeled: the fragment sets drain one per plane, and the registers they free take the
-        // NEXT chunk's 4x4 window one row per plane -- its latency hides under ~3 planes of MFMAs instead of
-        // being exposed at the chunk boundary
-        const unsigned wmn = chunk + 1 < nchunks ? wmask : 0u;
-        const int wsoff = (chunk + 1) * (WCK * 4);
-        HP3D_SCHED_BARRIER();
-        b_fetch(3, soff_of(chunk * 16 + 15));
-        plane_mma(12, 0);
-        HP3D_SCHED_BARRIER();
-        window_fetch_row(0, wmn, wsoff);
-        plane_mma(13, 1);
-        HP3D_SCHED_BARRIER();
-        window_fetch_row(1, wmn, wsoff);
-        plane_mma(14, 2);
-        HP3D_SCHED_BARRIER();
-        window_fetch_row(2, wmn, wsoff);
-        plane_mma(15, 3);
-        HP3D_SCHED_BARRIER();
-        window_fetch_row(3, wmn, wsoff);
-        fold(15, tmp[1]);
+        if (n_item >= nitems) break;
+        item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
     }
-
-    // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store ----------------------------------------
-    const int co = n0 + wave * 32 + li;
-    const float bias = p.bias[co];
-    const bool cok = co < p.cout_store;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int t = (r & 3) + 8 * (r >> 2) + 4 * lh;      // MFMA row = Winograd tile
-        const int off = tinfo[t], fl = tinfo[WTILES + t];
-        float v[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            float x = y[o][r] + bias;
-            if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
-            v[o] = x;
-        }
-        if (!cok || off < 0) continue;
-        float* o0 = p.out + off + co;
-        if (POOL) {
-            *o0 = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-        } else {
-            o0[0] = v[0];
-            if (fl & 1) o0[p.out_cs] = v[1];
-            if (fl & 2) o0[(size_t)Ws * p.out_cs] = v[2];
-            if (fl == 3) o0[(size_t)(Ws + 1) * p.out_cs] = v[3];
-        }
+    // the last workgroup to leave re-arms the counters for the next launch on this stream (every workgroup's
+    // final atomicAdd on sched[0] precedes its increment of sched[1])
+    if (tid == 0 && atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) {
+        atomicExch(p.sched, 0);
+        atomicExch(p.sched + 1, 0);
     }
 }
 
@@ -263,7 +328,7 @@ void wino_pack_weights(const float* g_hwio /*[3][3][Cin][Cout]*/, int Cin, int C
 // mode 1 (auto): only when the grid fills the chip (small problems stay on the direct kernel's small-batch
 // plan); mode 2 (forced, tests): whenever the shape allows
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B) {
-    if (mode == 0 || k != 3 || stride != 1 || Cin % 32 || Cout % 128) return 0;
+    if (mode == 0 || k != 3 || stride != 1 || Cin % 64 || Cout % 128) return 0;
     // the kernel addresses both tensors with 32-bit offsets (channel strides up to 2x the channel count)
     if ((long)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 8 >= (1L << 31)) return 0;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
@@ -279,12 +344,15 @@ int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
         attr_done = true;
     }
     // 32-bit byte / element offsets inside the kernel (buffer loads, the tile table)
-    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs >= (1L << 31)) return -1;
+    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
+    if (!pin.sched) return -1;
     ConvParams p = pin;
     p.tiles_x = (p.Wo + 1) / 2;          // Winograd tiles per row / column
     p.tiles_y = (p.Ho + 1) / 2;
     const long tiles = (long)p.B * p.tiles_x * p.tiles_y;
-    dim3 grid((unsigned)((tiles + WTILES - 1) / WTILES), p.Cout / 128);
+    const long items = (tiles + WTILES - 1) / WTILES * (p.Cout / 128);
+    static const int slots = hp3d_num_cus();              // persistent grid: one workgroup per CU
+    dim3 grid((unsigned)(items < slots ? items : slots));
     if (pool) {
         auto k = conv_wino_kernel<true>;
         HP3D_LAUNCH(k, grid, dim3(256), WINO_SMEM_BYTES, s, p);

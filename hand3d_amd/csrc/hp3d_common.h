@@ -54,11 +54,15 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
+// 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
+#define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
 #else
 typedef int hp3d_rsrc_t;
 #define HP3D_MAKE_RSRC(ptr, bytes) 0
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) (f32x4{0.f, 0.f, 0.f, 0.f})
+#define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc))
 #endif
 #endif
 

@@ -56,8 +56,8 @@ const char* hp3d_last_error(hp3d_ctx* ctx);          /* ctx may be NULL: last gl
 void* hp3d_stream(hp3d_ctx* ctx);                    /* the hipStream_t all work is queued on */
 int hp3d_sync(hp3d_ctx* ctx);
 /* options: "empty_reduce" = "inf" | "fltmax" (oracle/general.py EMPTY_REDUCE);
- *          "conv_impl"    = "mfma" (default: direct MFMA kernel, Winograd F(2x2,3x3) for the 3x3 layers whose
- *                            grid fills the chip) | "direct" (never Winograd) | "winograd" (whenever the shape
+ *          "conv_impl"    = "mfma" (default: direct MFMA kernel, float32 Winograd F(2x2,3x3) for the 3x3/stride-1
+ *                            layers with Cin%64==0, Cout%128==0 whose grid fills the chip) | "direct" (never Winograd) | "winograd" (whenever the shape
  *                            allows) | "naive" (debug cross-check kernel, never a fallback).               */
 int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value);
 

@@ -182,6 +182,10 @@ def main():
                     "share_of_gpu_time": round(ms / total_ms, 4)}
         dom = max(fam, key=lambda k: fam[k][0])
         roof = roof_of(dom)
+        if dom == 'conv_wino':
+            roof["note"] = ("achieved = direct-form (algorithmic) FLOPs / time; the kernel is float32 Winograd F(2x2,3x3), "
+                            "which executes 16/36 of them, so frac can exceed 1; mfma_executed_frac is the matrix-core "
+                            "utilisation against the same dense f32 peak")
         # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
         # scripts/summarize_prof.py -> profiles/<family>_traffic.json); counters cannot be read in-process.
         roof["traffic"] = None

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--layers', action='store_true', help='print the per-layer table to stderr')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'],
                     help="f32 = exact f32 MFMA (headline); f16 = half-precision trunks, BASELINE config 5 (looser parity)")
+    ap.add_argument('--comm', default='torch', choices=['torch', 'native'],
+                    help="weight broadcast: torch.distributed (RCCL) or the engine's own hp3d_comm_init + hp3d_bcast_weights")
     ap.add_argument('--streams', type=int, default=1, help='engine contexts (HIP streams) per GPU; the per-GPU batch is split across them')
     return ap.parse_args()
 
@@ -98,7 +100,10 @@ def main():
     eng = Engine(local)     # raises if libhp3d.so is missing: no fallback
     B, H, W = a.batch, a.height, a.width
     weights = synth.make_weights() if rank == 0 else None
-    ShardedPipeline(eng, rank, world).sync_weights(weights, device=dev, dtype=a.dtype)
+    if a.comm == 'native':
+        ShardedPipeline(eng, rank, world).sync_weights_native(weights, dtype=a.dtype)
+    else:
+        ShardedPipeline(eng, rank, world).sync_weights(weights, device=dev, dtype=a.dtype)
     # extra contexts on the same GPU: independent HIP streams whose kernels overlap (one context's tail /
     # prologue / launch gaps are filled by the other's bulk); they get the weights by a device-to-device blob copy
     engines = [eng]

@@ -58,7 +58,15 @@ _SIGNATURES = {
     'hp3d_prof_count': (C.c_int, [_ctx]),
     'hp3d_prof_get': (C.c_int, [_ctx, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float),
                                 C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'hp3d_get_timing': (C.c_int, [_ctx, C.POINTER(C.c_float), C.c_int]),
+    'hp3d_comm_unique_id': (C.c_int, [C.c_void_p]),
+    'hp3d_comm_init': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_bcast_weights': (C.c_int, [_ctx, C.c_int]),
+    'hp3d_allgather': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'hp3d_comm_destroy': (C.c_int, [_ctx]),
 }
+COMM_ID_BYTES = 128
+TIMING_STAGES = ('HandSegNet', 'mask_crop', 'PoseNet2D', 'lifting', 'total')
 EXPORTS = tuple(sorted(_SIGNATURES))
 
 _lib = None
@@ -343,6 +351,36 @@ class Engine(object):
     # -- measurement -------------------------------------------------------------------------
     def set_profiling(self, on):
         self._chk(self.lib.hp3d_set_profiling(self.h, int(on)))
+
+    def get_timing(self):
+        """{stage: GPU ms} over the profiled launches (hp3d_get_timing; stages: TIMING_STAGES)."""
+        buf = (C.c_float * len(TIMING_STAGES))()
+        self._chk(self.lib.hp3d_get_timing(self.h, buf, len(TIMING_STAGES)))
+        return dict(zip(TIMING_STAGES, [float(v) for v in buf]))
+
+    # -- multi-GPU: native RCCL on the engine stream (SURVEY.md 8e) -------------------------------
+    def comm_unique_id(self):
+        """128-byte RCCL id (create on ONE rank, hand to the others through the launcher's side channel)."""
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        self._chk(self.lib.hp3d_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def comm_init(self, rank, world, unique_id):
+        assert len(unique_id) == COMM_ID_BYTES
+        self._chk(self.lib.hp3d_comm_init(self.h, int(rank), int(world), C.c_char_p(bytes(unique_id))))
+
+    def bcast_weights(self, root=0):
+        self._chk(self.lib.hp3d_bcast_weights(self.h, int(root)))
+
+    def allgather(self, local, world):
+        """all-gather of equal-sized float32 arrays: [n, ...] per rank -> [world * n, ...]."""
+        a = _f32(local)
+        out = np.empty((int(world) * a.shape[0],) + a.shape[1:], np.float32)
+        self._chk(self.lib.hp3d_allgather(self.h, _ptr(a), a.size, _ptr(out)))
+        return out
+
+    def comm_destroy(self):
+        self._chk(self.lib.hp3d_comm_destroy(self.h))
 
     def profile(self):
         """[(layer, kernel, ms, flops, bytes)] of the last whole-path call."""

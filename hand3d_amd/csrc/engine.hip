@@ -11,6 +11,10 @@
 #include <map>
 #include <string>
 #include <vector>
+#ifndef HP3D_EMU
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library is dlopen'ed on first use (573 MB), never linked
+#endif
 
 namespace {
 
@@ -220,6 +224,8 @@ struct hp3d_ctx {
           *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
           *d_pooled = nullptr, *d_fcpart = nullptr;
     int* d_sched = nullptr;      // conv_wino work-queue counters (zero between launches)
+    void* comm = nullptr;        // ncclComm_t (hp3d_comm_init)
+    int comm_rank = 0, comm_size = 1;
     int* d_seed = nullptr;
     unsigned long long* d_keys = nullptr;
     unsigned char* d_det = nullptr;
@@ -832,6 +838,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
                     &ctx->d_pooled, &ctx->d_fcpart};
     for (float** p : fp)
         if (*p) hipFree(*p);
+    if (ctx->comm) hp3d_comm_destroy(ctx);
     if (ctx->d_sched) hipFree(ctx->d_sched);
     if (ctx->d_seed) hipFree(ctx->d_seed);
     if (ctx->d_keys) hipFree(ctx->d_keys);
@@ -1361,5 +1368,145 @@ int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, 
     if (bytes) *bytes = r.bytes;
     return 0;
 }
+
+int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {
+    if (!ctx || !ms_per_stage || n < 1) return HP3D_ERR_ARG;
+    float acc[HP3D_TIMING_STAGES] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (const ProfRec& r : ctx->prof) {
+        float ms = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(r.e1));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, r.e0, r.e1));
+        int st = 1;                                                        // glue: softmax / mask / crop
+        if (r.name.rfind("HandSegNet/", 0) == 0) st = 0;
+        else if (r.name.rfind("PoseNet2D/", 0) == 0 || r.name == "kp_upsample") st = 2;
+        else if (r.name.rfind("PosePrior/", 0) == 0 || r.name.rfind("ViewpointNet/", 0) == 0 || r.name == "lift_epilogue" ||
+                 r.name == "concat_handside" || r.name.rfind("fc", 0) == 0) st = 3;
+        acc[st] += ms;
+        acc[4] += ms;
+    }
+    for (int i = 0; i < n && i < HP3D_TIMING_STAGES; ++i) ms_per_stage[i] = acc[i];
+    return 0;
+}
+
+// ---- RCCL (loaded lazily) ----------------------------------------------------------------------------------------
+#ifndef HP3D_EMU
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl* rccl(hp3d_ctx* ctx) {
+    static Rccl R;
+    if (R.h) return &R;
+    // a process that already carries an RCCL (e.g. torch's) gets that one: same SONAME
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { set_error(ctx, "librccl not found (dlopen)"); return nullptr; }
+    R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    R.CommInitRank = (decltype(R.CommInitRank))dlsym(h, "ncclCommInitRank");
+    R.Broadcast = (decltype(R.Broadcast))dlsym(h, "ncclBroadcast");
+    R.AllGather = (decltype(R.AllGather))dlsym(h, "ncclAllGather");
+    R.CommDestroy = (decltype(R.CommDestroy))dlsym(h, "ncclCommDestroy");
+    R.GetErrorString = (decltype(R.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!R.GetUniqueId || !R.CommInitRank || !R.Broadcast || !R.AllGather || !R.CommDestroy || !R.GetErrorString) {
+        set_error(ctx, "librccl lacks an expected symbol");
+        return nullptr;
+    }
+    R.h = h;
+    return &R;
+}
+#define NCCLCHK(ctx, R, call)                                                          \
+    do {                                                                               \
+        ncclResult_t _r = (call);                                                      \
+        if (_r != ncclSuccess) HP3D_FAIL(ctx, HP3D_ERR_HIP, "%s: %s", #call, (R)->GetErrorString(_r)); \
+    } while (0)
+}  // namespace
+
+int hp3d_comm_unique_id(void* id128) {
+    if (!id128) return HP3D_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == HP3D_COMM_ID_BYTES, "ncclUniqueId size");
+    Rccl* R = rccl(nullptr);
+    if (!R) return HP3D_ERR_UNSUPPORTED;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) { set_error(nullptr, "ncclGetUniqueId failed"); return HP3D_ERR_HIP; }
+    memcpy(id128, &id, sizeof(id));
+    return 0;
+}
+int hp3d_comm_init(hp3d_ctx* ctx, int rank, int nranks, const void* id128) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return HP3D_ERR_ARG;
+    if (ctx->comm) HP3D_FAIL(ctx, HP3D_ERR_ARG, "communicator already initialised");
+    Rccl* R = rccl(ctx);
+    if (!R) return HP3D_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t c = nullptr;
+    NCCLCHK(ctx, R, R->CommInitRank(&c, nranks, id, rank));
+    ctx->comm = c; ctx->comm_rank = rank; ctx->comm_size = nranks;
+    return 0;
+}
+int hp3d_bcast_weights(hp3d_ctx* ctx, int root) {
+    if (!ctx || !ctx->comm || root < 0 || root >= ctx->comm_size) return HP3D_ERR_ARG;
+    Rccl* R = rccl(ctx);
+    if (!R) return HP3D_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    ncclComm_t c = (ncclComm_t)ctx->comm;
+    const bool is_root = ctx->comm_rank == root;
+    if (is_root && !ctx->blob) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "root has no finalized weights");
+    // header: nets mask (bit 5 = half-precision section live); the blob layout is identical on every rank
+    Scratch S(ctx);
+    int* d_hdr = S.alloc<int>(2); NN(ctx, d_hdr);
+    int hdr[2] = {is_root ? hp3d_nets_mask(ctx) : 0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(d_hdr, hdr, sizeof(hdr), hipMemcpyHostToDevice, ctx->stream));
+    NCCLCHK(ctx, R, R->Broadcast(d_hdr, d_hdr, 2, ncclInt, root, c, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hdr, d_hdr, sizeof(hdr), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const int mask = hdr[0], f16 = (mask & 32) ? 1 : 0;
+    if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
+    NCCLCHK(ctx, R, R->Broadcast(ctx->blob, ctx->blob, ctx->T.blob_floats, ncclFloat, root, c, ctx->stream));
+    if (f16) {
+        if (!ctx->blob16) CHK(dev_realloc(ctx, &ctx->blob16, ctx->T.blob16_halves));
+        NCCLCHK(ctx, R, R->Broadcast(ctx->blob16, ctx->blob16, ctx->T.blob16_halves, ncclHalf, root, c, ctx->stream));
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nets = mask & 31;
+    ctx->prec = f16;
+    return 0;
+}
+int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv_host) {
+    if (!ctx || !ctx->comm || !send_host || !recv_host || count < 1) return HP3D_ERR_ARG;
+    Rccl* R = rccl(ctx);
+    if (!R) return HP3D_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    float* d_send = S.upload(send_host, (size_t)count); NN(ctx, d_send);
+    float* d_recv = S.alloc<float>((size_t)count * ctx->comm_size); NN(ctx, d_recv);
+    NCCLCHK(ctx, R, R->AllGather(d_send, d_recv, (size_t)count, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(recv_host, d_recv, sizeof(float) * count * ctx->comm_size, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int hp3d_comm_destroy(hp3d_ctx* ctx) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!ctx->comm) return 0;
+    Rccl* R = rccl(ctx);
+    if (R) R->CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->comm_size = 1; ctx->comm_rank = 0;
+    return 0;
+}
+#else   // the CPU interpreter build has no RCCL
+int hp3d_comm_unique_id(void*) { return HP3D_ERR_UNSUPPORTED; }
+int hp3d_comm_init(hp3d_ctx* ctx, int, int, const void*) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
+int hp3d_bcast_weights(hp3d_ctx* ctx, int) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
+int hp3d_allgather(hp3d_ctx* ctx, const float*, int, float*) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
+int hp3d_comm_destroy(hp3d_ctx*) { return 0; }
+#endif
 
 }  // extern "C"

@@ -50,12 +50,31 @@ def gather_keypoints(local_kp, n_total=None, group=None):
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], 0)
 
 
+def native_comm_init(engine, rank, world, group=None):
+    """Set up the engine's own RCCL communicator (include/hp3d.h hp3d_comm_*): rank 0 draws the 128-byte id, the
+    launcher's process group (any backend) only carries those bytes to the other ranks."""
+    import torch.distributed as dist
+    ids = [engine.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0, group=group)
+    engine.comm_init(rank, world, ids[0])
+
+
 class ShardedPipeline(object):
     """One rank's share of a sharded batch: engine + device-resident I/O (torch tensors are used
     only as device memory).  `weights` is needed on rank 0 only."""
 
     def __init__(self, engine, rank=0, world=1, group=None):
         self.engine, self.rank, self.world, self.group = engine, rank, world, group
+
+    def sync_weights_native(self, weights=None, dtype=0):
+        """Same as sync_weights through the C ABI only: hp3d_comm_init + hp3d_bcast_weights (RCCL on the engine's
+        stream, no torch tensors)."""
+        if self.rank == 0:
+            self.engine.load_weight_dict(weights)
+            self.engine.finalize_weights(dtype)
+        native_comm_init(self.engine, self.rank, self.world, self.group)
+        self.engine.bcast_weights(0)
 
     def sync_weights(self, weights=None, device=None, dtype=0):
         import torch

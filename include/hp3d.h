@@ -160,6 +160,25 @@ int hp3d_set_profiling(hp3d_ctx* ctx, int on);
 int hp3d_prof_count(hp3d_ctx* ctx);
 int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, int kernel_cap,
                   float* ms, double* flops, double* bytes);
+/* Per-stage GPU milliseconds of the profiled launches (SURVEY.md 8b `hp3d_get_timing`):
+ * [0] HandSegNet, [1] mask / box / crop glue, [2] PoseNet2D (+ heat-map upsample), [3] PosePrior + ViewpointNet +
+ * lifting epilogue, [4] everything.  Writes min(n, 5) values; needs hp3d_set_profiling(ctx, 1 | 2).  */
+#define HP3D_TIMING_STAGES 5
+int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
+
+/* ---- multi-GPU: one process and one context per GPU, RCCL over xGMI ---------
+ * The path has no data-path collective.  These are the two exchanges it needs, on the context's own stream:
+ * the one-off broadcast of the packed weight blob (replaces every rank un-pickling + re-packing 140 MB) and the
+ * all-gather of per-shard results (keypoints: 252 B per image).  librccl is loaded on first use (dlopen), not
+ * linked.  The 128-byte id is produced on one rank and handed to the others by the launcher (torch.distributed
+ * store, MPI, a file ...); `hp3d_bcast_weights` on a non-root rank replaces that rank's weights (any nets mask /
+ * precision the root finalized).                                                                  */
+#define HP3D_COMM_ID_BYTES 128
+int hp3d_comm_unique_id(void* id128);
+int hp3d_comm_init(hp3d_ctx* ctx, int rank, int nranks, const void* id128);
+int hp3d_bcast_weights(hp3d_ctx* ctx, int root);
+int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv_host /* [nranks * count] */);
+int hp3d_comm_destroy(hp3d_ctx* ctx);
 
 #ifdef __cplusplus
 }

@@ -486,3 +486,36 @@ def test_errors_are_loud(gpu_engine):
     with pytest.raises(AssertionError):
         gpu_engine.handsegnet(np.zeros((1, 100, 100, 3), np.float32))   # H,W not multiples of 8
     e2.close()
+
+
+def test_stage_timing_and_native_rccl_world1(net, synth_weights):
+    """hp3d_get_timing (per-stage GPU ms) and the engine's own RCCL entry points (hp3d_comm_* / hp3d_bcast_weights /
+    hp3d_allgather) at world size 1 -- the only size a one-GPU box offers: librccl is dlopen'ed, a communicator is
+    built from a fresh id, the weight broadcast is an identity and the all-gather returns the local shard."""
+    img = synth.make_batch(77, 2, 240, 320)
+    hs = synth.hand_sides(2)
+    eng = net.engine
+    before = eng.infer_full(img, hs)
+    eng.set_profiling(1)
+    eng.infer_full(img, hs)
+    t = eng.get_timing()
+    rows = eng.profile()
+    eng.set_profiling(0)
+    assert abs(t['total'] - sum(r[2] for r in rows)) < 1e-3 * max(t['total'], 1.0)
+    assert t['HandSegNet'] > 0 and t['PoseNet2D'] > 0 and t['lifting'] > 0 and t['mask_crop'] > 0
+    assert abs(t['HandSegNet'] + t['mask_crop'] + t['PoseNet2D'] + t['lifting'] - t['total']) < 1e-3 * t['total']
+    uid = eng.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    eng.comm_init(0, 1, uid)
+    try:
+        with pytest.raises(AssertionError):
+            eng.comm_init(0, 1, uid)                    # already initialised
+        eng.bcast_weights(0)
+        after = eng.infer_full(img, hs)
+        for k in ('scoremap', 'kpmap', 'coord3d', 'center', 'scale'):
+            assert np.array_equal(before[k], after[k]), k
+        g = eng.allgather(before['coord3d'], 1)
+        assert np.array_equal(g, before['coord3d'])
+    finally:
+        eng.comm_destroy()
+    eng.comm_destroy()                                  # idempotent

@@ -81,3 +81,16 @@ def test_incomplete_network_is_rejected(emu_engine, synth_weights):
     with pytest.raises(Hp3dError):
         e2.finalize_weights()
     e2.close()
+
+
+def test_timing_and_comm_entry_points_on_interpreter(emu_engine, synth_weights):
+    """hp3d_get_timing needs no GPU; the RCCL entry points exist in the CPU interpreter build but refuse to run
+    (HP3D_ERR_UNSUPPORTED -> NotImplementedError), they never pretend."""
+    t = emu_engine.get_timing()
+    assert set(t) == {'HandSegNet', 'mask_crop', 'PoseNet2D', 'lifting', 'total'} and t['total'] == 0.0
+    with pytest.raises(NotImplementedError):
+        emu_engine.comm_init(0, 1, b'\0' * 128)
+    with pytest.raises(NotImplementedError):
+        emu_engine.bcast_weights(0)
+    with pytest.raises(AssertionError):
+        emu_engine.comm_init(0, 1, b'short')

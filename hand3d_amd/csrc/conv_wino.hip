@@ -31,24 +31,40 @@
 
 namespace {
 
-constexpr int WCK = 32;                        // channels per step
-constexpr int WLDA = WCK + 4;                  // V row pitch in floats (144 B)
-constexpr int WTILES = 32;                     // Winograd tiles per work item
-constexpr int PLANE_FLOATS = WTILES * WLDA;    // one plane of one buffer
-constexpr int VBUF_FLOATS = 16 * PLANE_FLOATS; // 73728 B
-constexpr int WINO_SMEM_BYTES = 2 * VBUF_FLOATS * 4 + 2 * 2 * WTILES * 4 + 16;     // 2 V buffers + two tile tables + next-item slot
+// Two shapes of work item (template parameter NT = Winograd tiles per item):
+//   NT = 32: 32 tiles x 128 couts, 32-channel steps, V pitch 36 floats (padding keeps ds_read_b128 conflict-free);
+//   NT = 64: 64 tiles x  64 couts, 16-channel steps (layers with Cout % 128 != 0: conv1_2 64 -> 64): wave w owns
+//            couts 32 (w & 1) .. +31 of tiles 32 (w >> 1) .. +31; V pitch 16 floats with the channel quad XOR-swizzled
+//            by (tile >> 2) & 3 instead of padding (2 x 64 KB must fit next to the tables).
+template <int NT> struct WinoCfg {
+    static constexpr int CK = NT == 32 ? 32 : 16;           // channels per step
+    static constexpr int NQ = CK / 4;                        // channel quads per step (loader threads per tile)
+    static constexpr int G = CK / 8;                         // 16-B fragments per lane, plane and step (4 MFMAs each)
+    static constexpr int LDA = NT == 32 ? 36 : 16;           // V row pitch in floats
+    static constexpr int COUTS = NT == 32 ? 128 : 64;        // output channels per item
+    static constexpr int PLANE_FLOATS = NT * LDA;            // one plane of one buffer
+    static constexpr int VBUF_FLOATS = 16 * PLANE_FLOATS;    // 73728 B / 65536 B
+    static constexpr int SMEM_BYTES = 2 * VBUF_FLOATS * 4 + 2 * 2 * NT * 4 + 16;     // 2 V buffers + two tile tables + next-item slot
+    static constexpr int PL_PER_BASE = NT == 32 ? 14 : 16;   // planes reachable from one ds_read base (16-bit immediate)
+};
 
-template <bool POOL>
+template <bool POOL, int NT>
 HP3D_KERNEL2(256, 1)
 void conv_wino_kernel(const ConvParams p) {
+    using Cfg = WinoCfg<NT>;
+    constexpr int WCK = Cfg::CK, WLDA = Cfg::LDA, WTILES = NT, PLANE_FLOATS = Cfg::PLANE_FLOATS, VBUF_FLOATS = Cfg::VBUF_FLOATS;
+    constexpr int NQ = Cfg::NQ, G = Cfg::G, COUTS = Cfg::COUTS;
     HP3D_DYN_SMEM(V);
-    // tile tables, double buffered by item parity: [0..31] output offset of tile t (-1: no such tile), [32..63] edge flags;
+    // tile tables, double buffered by item parity: [0..NT-1] output offset of tile t (-1: no such tile), [NT..2NT-1] edge flags;
     // then one slot for the next item's number
     int* tinfo = (int*)(V + 2 * VBUF_FLOATS);
     int* next_slot = tinfo + 4 * WTILES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
+    const int wcout = NT == 32 ? wave : (wave & 1);           // this wave's 32-cout block inside the item
+    const int tbase = NT == 32 ? 0 : (wave >> 1) * 32;        // ... and its first tile
+    auto swz = [](int t) { return NT == 32 ? 0 : ((t >> 2) & 3); };      // quad swizzle of tile t's V row
 
     // Work item = (cout block of 128) x (32 Winograd tiles).  The 32 tiles are consecutive entries of the
     // flattened (image, band of 4 tile rows, tile column, row in band) order: a 4x8 footprint where the tile
@@ -56,7 +72,8 @@ void conv_wino_kernel(const ConvParams p) {
     // blocks), and an item may continue into the next image.
     const int TXn = p.tiles_x, TYn = p.tiles_y, per_img = TXn * TYn;
     const int tile_blocks = (p.B * per_img + WTILES - 1) / WTILES;
-    const int nitems = tile_blocks * (p.Cout >> 7);
+    const int ncy = p.Cout / COUTS;
+    const int nitems = tile_blocks * ncy;
     auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) {
         tb = id / per_img;
         const int r = id - tb * per_img;
@@ -86,7 +103,7 @@ void conv_wino_kernel(const ConvParams p) {
 
     // ---- loader role: this thread transforms the 4x4 window of tile lt for channel quad lc --------------
     // (buffer loads: a window element outside the image gets an out-of-range offset and reads as 0)
-    const int lt = tid >> 3, lc = tid & 7;
+    const int lt = tid / NQ, lc = tid % NQ;
     const int cs4 = p.in_cs * 4;
     constexpr int OOR = (int)0x80000000;
     int wv[16];               // byte offsets of the 16 window elements (OOR: zero padding)
@@ -121,7 +138,7 @@ void conv_wino_kernel(const ConvParams p) {
             t[2 * 4 + c] = d[2 * 4 + c] - d[1 * 4 + c];
             t[3 * 4 + c] = d[1 * 4 + c] - d[3 * 4 + c];
         }
-        float* Vq = V + buf * VBUF_FLOATS + lt * WLDA + lc * 4;
+        float* Vq = V + buf * VBUF_FLOATS + lt * WLDA + (lc ^ swz(lt)) * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const f32x4 v0 = t[r * 4 + 0] - t[r * 4 + 2];
@@ -141,25 +158,38 @@ void conv_wino_kernel(const ConvParams p) {
     const int CO32 = p.Cout >> 5;
     const int nsteps = p.Cin / WCK;
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(16 * p.Cin) * (unsigned)p.Cout * 4u);
-    const int step_stride_b = CO32 * 4096;                  // bytes between 32-channel steps
-    const int plane_stride_b = nsteps * step_stride_b;      // bytes between planes
-    auto soff_of = [&](int plane, int step) { return plane * plane_stride_b + step * step_stride_b; };
+    const int chunk_stride_b = CO32 * 4096;                         // bytes between 32-channel chunks
+    const int plane_stride_b = (p.Cin >> 5) * chunk_stride_b;       // bytes between planes
+    // a 16-channel step is one half (g = 0,1 / 2,3: 2 KB) of a 32-channel chunk
+    auto soff_of = [&](int plane, int step) {
+        return NT == 32 ? plane * plane_stride_b + step * chunk_stride_b
+                        : plane * plane_stride_b + (step >> 1) * chunk_stride_b + (step & 1) * 2048;
+    };
 
     f32x16 M[16];          // the 16 plane accumulators (AGPRs), live across the whole item
-    f32x4 bq[4][4];        // B fragments of four planes in flight: prefetch distance 3 planes
+    f32x4 bq[4][G];        // B fragments of four planes in flight
     auto b_fetch = [&](int set, int voff, int soff) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[set][g] = HP3D_BUFFER_LOAD16(wrsrc, voff + g * 1024, soff);
+        for (int g = 0; g < G; ++g) bq[set][g] = HP3D_BUFFER_LOAD16(wrsrc, voff + g * 1024, soff);
     };
-    // A fragments: this lane's row of the current V buffer; two bases so that every ds_read offset fits the
-    // 16-bit immediate (an address add per read would be a VALU instruction in the MFMA stream)
-    const int va_lane = (li * WLDA + lh * 4) * 4;
+    // A fragments: this lane's row (tile tbase + li) of the current V buffer, fragment g = channels 8g + 4 lh .. +3,
+    // i.e. quad 2g + lh.  NT = 32: one base per 14 planes so that every ds_read offset fits the 16-bit immediate (an
+    // address add per read would be a VALU instruction in the MFMA stream), g is an immediate; NT = 64: the quad is
+    // swizzled, so g = 0 / 1 have their own base (they differ in address bit 5), all 16 planes fit the immediate.
+    const int arow = tbase + li;
+    const int va_lane0 = (arow * WLDA + ((lh) ^ swz(arow)) * 4) * 4;
+    const int va_lane1 = (arow * WLDA + ((2 + lh) ^ swz(arow)) * 4) * 4;
     int ab0 = 0, ab1 = 0;
-    f32x4 af[2][4];
+    f32x4 af[2][G];
     auto a_fetch = [&](int set, int plane) {
-        const int base = plane < 14 ? ab0 : ab1, pl = plane < 14 ? plane : plane - 14;
+        if (NT == 32) {
+            const int base = plane < 14 ? ab0 : ab1, pl = plane < 14 ? plane : plane - 14;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) af[set][g] = *(const f32x4*)((const char*)V + base + (pl * PLANE_FLOATS + g * 8) * 4);
+            for (int g = 0; g < G; ++g) af[set][g] = *(const f32x4*)((const char*)V + base + (pl * PLANE_FLOATS + g * 8) * 4);
+        } else {
+            af[set][0] = *(const f32x4*)((const char*)V + ab0 + plane * PLANE_FLOATS * 4);
+            af[set][G - 1] = *(const f32x4*)((const char*)V + ab1 + plane * PLANE_FLOATS * 4);
+        }
     };
 
     // ---- first item: the only exposed prologue -------------------------------------------------------------
@@ -167,7 +197,7 @@ void conv_wino_kernel(const ConvParams p) {
     int cy = item / tile_blocks, tblock = item - cy * tile_blocks;
     loader_setup(tblock, true);
     table_write(tblock, 0);
-    int wvoff = (cy * 4 + wave) * 4096 + lane * 16;
+    int wvoff = (cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
     window_fetch(0);
     b_fetch(0, wvoff, soff_of(0, 0));
     b_fetch(1, wvoff, soff_of(1, 0));
@@ -180,10 +210,10 @@ void conv_wino_kernel(const ConvParams p) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff;
         int n_item = nitems;
         if (tid == 0) *next_slot = (int)gridDim.x + atomicAdd(p.sched, 1);      // read after the barrier that ends step 0
-        const int co = cy * 128 + wave * 32 + li;
+        const int co = cy * COUTS + wcout * 32 + li;
         const float bias = p.bias[co];           // in flight during the item, used in the epilogue
 
-        // one 32-channel step: 16 planes x 16 MFMAs on V[cur]; the first step of an item starts the accumulators
+        // one step (32 or 16 channels): 16 planes x 16 or 8 MFMAs on V[cur]; the first step of an item starts the accumulators
         // from the inline constant 0
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -194,8 +224,8 @@ void conv_wino_kernel(const ConvParams p) {
             // next item's first) then have 4 planes (~1.8 us) to arrive before anything depends on them.
             const int nvoff = lasts ? n_wvoff : wvoff;
             const int nstep = lasts ? 0 : step + 1;
-            ab0 = cur * (VBUF_FLOATS * 4) + va_lane;
-            ab1 = ab0 + 14 * PLANE_FLOATS * 4;
+            ab0 = cur * (VBUF_FLOATS * 4) + va_lane0;
+            ab1 = NT == 32 ? ab0 + 14 * PLANE_FLOATS * 4 : cur * (VBUF_FLOATS * 4) + va_lane1;
             HP3D_OPAQUE_V(ab0);
             HP3D_OPAQUE_V(ab1);
             a_fetch(0, 0);                       // first: plane 0's MFMAs wait for exactly this
@@ -212,14 +242,14 @@ void conv_wino_kernel(const ConvParams p) {
                     M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], M[pl]);
                 }
 #pragma unroll
-                for (int gj = 1; gj < 16; ++gj)
+                for (int gj = 1; gj < 4 * G; ++gj)
                     M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
                 if (pl == 0) {               // the window loads are issued between plane 0's MFMAs, not in front of them
                     window_fetch(lasts ? 0 : (step + 1) * (WCK * 4));
-                    HP3D_SCHED_GROUP(HP3D_SG_DS_READ, 4);
+                    HP3D_SCHED_GROUP(HP3D_SG_DS_READ, G);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        HP3D_SCHED_GROUP(HP3D_SG_MFMA, 2);
+                        HP3D_SCHED_GROUP(HP3D_SG_MFMA, G / 2);
                         HP3D_SCHED_GROUP(HP3D_SG_VMEM_READ, 2);
                     }
                 }
@@ -241,7 +271,7 @@ void conv_wino_kernel(const ConvParams p) {
             n_cy = has_next ? n_item / tile_blocks : cy;
             n_tblock = has_next ? n_item - n_cy * tile_blocks : tblock;
             table_write(n_tblock, (k + 1) & 1);
-            n_wvoff = (n_cy * 4 + wave) * 4096 + lane * 16;
+            n_wvoff = (n_cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
         }
         for (int step = 1; step < nsteps; ++step) step_body(step, std::false_type{});
 
@@ -256,7 +286,7 @@ void conv_wino_kernel(const ConvParams p) {
             int vo[4], fl[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int t = q + 8 * rg + 4 * lh;              // MFMA row = Winograd tile
+                const int t = tbase + q + 8 * rg + 4 * lh;      // MFMA row = Winograd tile
                 const int off = tab[t];
                 fl[q] = POOL ? 0 : tab[WTILES + t];
                 vo[q] = (cok && off >= 0) ? (off + co) * 4 : OOR;
@@ -326,23 +356,35 @@ void wino_pack_weights(const float* g_hwio /*[3][3][Cin][Cout]*/, int Cin, int C
 }
 
 // mode 1 (auto): only when the grid fills the chip (small problems stay on the direct kernel's small-batch
-// plan); mode 2 (forced, tests): whenever the shape allows
+// plan); mode 2 (forced, tests): whenever the shape allows.  Returns the tile count of the item shape (32: Cout %
+// 128 == 0, 64: Cout % 64 == 0) or 0.
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B) {
-    if (mode == 0 || k != 3 || stride != 1 || Cin % 64 || Cout % 128) return 0;
+    if (mode == 0 || k != 3 || stride != 1 || Cin % 32) return 0;
+    const int nt = Cout % 128 == 0 ? 32 : Cout % 64 == 0 ? 64 : 0;
+    if (!nt || (nt == 32 && Cin % 64)) return 0;              // at least two steps per item
     // the kernel addresses both tensors with 32-bit offsets (channel strides up to 2x the channel count)
     if ((long)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 8 >= (1L << 31)) return 0;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
-    const long blocks = (tiles + 31) / 32 * (Cout / 128);
-    return mode == 2 || blocks >= 256;
+    const long items = (tiles + nt - 1) / nt * (Cout / (nt == 32 ? 128 : 64));
+    return (mode == 2 || items >= 256) ? nt : 0;
+}
+
+template <bool POOL, int NT>
+static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
+    using Cfg = WinoCfg<NT>;
+    static bool attr_done = false;
+    auto k = conv_wino_kernel<POOL, NT>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
+        attr_done = true;
+    }
+    const long items = (tiles + NT - 1) / NT * (p.Cout / Cfg::COUTS);
+    static const int slots = hp3d_num_cus();              // persistent grid: one workgroup per CU
+    dim3 grid((unsigned)(items < slots ? items : slots));
+    HP3D_LAUNCH(k, grid, dim3(256), Cfg::SMEM_BYTES, s, p);
 }
 
 int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES);
-        (void)hipFuncSetAttribute((const void*)conv_wino_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_SMEM_BYTES);
-        attr_done = true;
-    }
     // 32-bit byte / element offsets inside the kernel (buffer loads, the tile table)
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
     if (!pin.sched) return -1;
@@ -350,15 +392,12 @@ int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
     p.tiles_x = (p.Wo + 1) / 2;          // Winograd tiles per row / column
     p.tiles_y = (p.Ho + 1) / 2;
     const long tiles = (long)p.B * p.tiles_x * p.tiles_y;
-    const long items = (tiles + WTILES - 1) / WTILES * (p.Cout / 128);
-    static const int slots = hp3d_num_cus();              // persistent grid: one workgroup per CU
-    dim3 grid((unsigned)(items < slots ? items : slots));
-    if (pool) {
-        auto k = conv_wino_kernel<true>;
-        HP3D_LAUNCH(k, grid, dim3(256), WINO_SMEM_BYTES, s, p);
+    if (p.Cout % 128 == 0) {
+        if (pool) wino_launch_t<true, 32>(p, tiles, s); else wino_launch_t<false, 32>(p, tiles, s);
+    } else if (p.Cout % 64 == 0) {
+        if (pool) wino_launch_t<true, 64>(p, tiles, s); else wino_launch_t<false, 64>(p, tiles, s);
     } else {
-        auto k = conv_wino_kernel<false>;
-        HP3D_LAUNCH(k, grid, dim3(256), WINO_SMEM_BYTES, s, p);
+        return -1;
     }
     return 0;
 }

@@ -48,7 +48,7 @@ struct ConvL {
     // packed geometry
     int ek, cin_pad, cout_pad;
     size_t w_off, b_off;   // offsets into the blob (floats)
-    size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%128==0), 0 = none
+    size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
     size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
     int net;
@@ -80,7 +80,7 @@ struct Tables {
         blob_floats += (size_t)l.ek * l.ek * l.cin_pad * l.cout_pad;
         l.b_off = blob_floats;
         blob_floats += l.cout_pad;
-        if (k == 3 && stride == 1 && l.mode == 0 && cout % 128 == 0) {     // Winograd F(2x2,3x3) copy (16 planes)
+        if (k == 3 && stride == 1 && l.mode == 0 && cout % 64 == 0) {      // Winograd F(2x2,3x3) copy (16 planes)
             l.ww_off = blob_floats;
             blob_floats += (size_t)16 * l.cin_pad * l.cout_pad;
         }
@@ -209,7 +209,7 @@ struct hp3d_ctx {
     int nets = 0;              // finalized nets mask
     int empty_fltmax = 0;
     int conv_naive = 0;
-    int use_wino = 1;          // 3x3/s1 layers with Cout%128==0 run as Winograd F(2x2,3x3) (conv_impl=direct disables)
+    int use_wino = 1;          // 3x3/s1 layers with Cout%64==0 run as Winograd F(2x2,3x3) (conv_impl=direct disables)
     // debug copies of the unpacked HWIO weights for conv_impl=naive
     std::map<std::string, float*> naive_w;
 
@@ -1171,7 +1171,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     l.mode = 0; l.ek = k; l.cin_pad = pad32(Cin); l.cout_pad = pad32(Cout);
     if (ctx->use_wino == 2 && !ctx->conv_naive && k == 3 && stride == 1) {       // conv_impl=winograd: no silent fallback
         l.cin_pad = (Cin + 63) / 64 * 64;
-        if (Cout % 128) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_impl=winograd needs Cout %% 128 == 0 (got %d)", Cout);
+        if (Cout % 64) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_impl=winograd needs Cout %% 64 == 0 (got %d)", Cout);
     }
     l.w_off = 0; l.b_off = (size_t)k * k * l.cin_pad * l.cout_pad;
     std::vector<float> packed(l.b_off + l.cout_pad);
@@ -1188,7 +1188,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
-    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B) && Cout % 128 == 0) {
+    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B) && Cout % 64 == 0) {
         const size_t wn = (size_t)16 * l.cin_pad * l.cout_pad;
         std::vector<float> pw(wn + l.cout_pad, 0.f);
         wino_pack_weights(w_hwio, Cin, Cout, l.cin_pad, l.cout_pad, pw.data());

@@ -152,7 +152,9 @@ def test_f16_trunk_mode_on_interpreter(emu_engine, synth_weights):
     assert not (emu_engine.nets_mask() & 32)
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 17, 21, 128, 256, 0), (2, 14, 20, 64, 128, 1)],
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 17, 21, 128, 256, 0), (2, 14, 20, 64, 128, 1),
+                                  # 64-tile x 64-cout items (16-channel steps, swizzled V): conv1_2-like, odd sizes, 3 cout blocks
+                                  (2, 16, 32, 64, 64, 1), (1, 17, 21, 32, 64, 0), (1, 12, 20, 96, 192, 0)],
                          ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
 def test_winograd_kernel_on_interpreter(emu_engine, case):
     """conv_wino.hip forced on (F(2x2,3x3)): input/weight/output transforms, fused pool, masked tiles."""

@@ -69,7 +69,9 @@ WINO_CASES = [(1, 60, 80, 256, 256, 1), (2, 30, 40, 512, 512, 0), (1, 64, 64, 12
               (2, 18, 22, 64, 128, 1), (1, 120, 160, 64, 128, 0), (4, 32, 32, 512, 256, 0),
               # more work items than CUs: the persistent grid walks several items per workgroup (work counter,
               # next-item prefetch, tile-table parity), three cout blocks, items that straddle images
-              (8, 64, 64, 128, 256, 0), (6, 48, 56, 64, 384, 1)]
+              (8, 64, 64, 128, 256, 0), (6, 48, 56, 64, 384, 1),
+              # Cout % 128 != 0: 64-tile x 64-cout items with 16-channel steps (conv1_2 is 64 -> 64 with the fused pool)
+              (2, 64, 64, 64, 64, 1), (1, 33, 47, 32, 64, 0), (3, 40, 40, 96, 192, 0), (8, 128, 128, 64, 64, 1)]
 
 
 @pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)

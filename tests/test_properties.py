@@ -27,6 +27,30 @@ def test_conv_random_geometry(emu_engine, H, W, Cin, Cout, ks, B, seed):
         assert np.abs(emu_engine.conv2d(x, w, b, 1, True, True) - T.max_pool_2x2(r)).max() < 2e-5
 
 
+@settings(max_examples=14, **COMMON)
+@given(H=st.integers(2, 15), W=st.integers(2, 15), Cin=st.integers(1, 100), Cout=st.sampled_from([64, 128, 192, 256]),
+       B=st.integers(1, 3), pool=st.booleans(), act=st.booleans(), seed=st.integers(0, 10 ** 6))
+def test_winograd_random_geometry(emu_engine, H, W, Cin, Cout, B, pool, act, seed):
+    """conv_wino.hip forced on, both item shapes (32 tiles x 128 couts / 64 tiles x 64 couts): odd sizes (half tiles at
+    the right / bottom edge), items that straddle images, several items per workgroup (the interpreter reports 3 CUs),
+    channel counts that need zero padding, with and without activation / fused pool."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('conv_impl', 'winograd')
+    try:
+        y = emu_engine.conv2d(x, w, b, 1, act, pool)
+    finally:
+        emu_engine.set_option('conv_impl', 'mfma')
+    assert y.shape == r.shape and (y.size == 0 or np.abs(y - r).max() < 2e-5)
+
+
 @settings(max_examples=15, **COMMON)
 @given(H=st.integers(24, 72), W=st.integers(32, 96), density=st.floats(0.05, 0.95), seed=st.integers(0, 10 ** 6),
        blocky=st.booleans())

@@ -58,7 +58,10 @@ int hp3d_sync(hp3d_ctx* ctx);
 /* options: "empty_reduce" = "inf" | "fltmax" (oracle/general.py EMPTY_REDUCE);
  *          "conv_impl"    = "mfma" (default: direct MFMA kernel, float32 Winograd F(2x2,3x3) for the 3x3/stride-1
  *                            layers with Cin%64==0, Cout%128==0 whose grid fills the chip) | "direct" (never Winograd) | "winograd" (whenever the shape
- *                            allows) | "naive" (debug cross-check kernel, never a fallback).               */
+ *                            allows) | "naive" (debug cross-check kernel, never a fallback);
+ *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N
+ *                            images ("0" = never split; default "auto" = 32 in float32 mode, no split with f16 trunks).
+ *                            Bit-identical to making the calls chunk by chunk.                               */
 int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value);
 
 /* ---- weights ----------------------------------------------------------------------------

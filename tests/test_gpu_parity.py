@@ -521,3 +521,31 @@ def test_stage_timing_and_native_rccl_world1(net, synth_weights):
     finally:
         eng.comm_destroy()
     eng.comm_destroy()                                  # idempotent
+
+
+def test_micro_batch_chunks_equal_separate_calls(net, synth_weights):
+    """hp3d_set_option("micro_batch", N): whole-path calls run as chunks of N images -- bit-identical to making the
+    calls chunk by chunk (an unsplit call can differ at rounding level: the small-batch conv plan depends on B), one
+    profile per call."""
+    img = synth.make_batch(4100, 5, 240, 320)
+    hs = synth.hand_sides(5)
+    eng = net.engine
+    eng.set_option('micro_batch', '0')
+    try:
+        whole = eng.infer_full(img, hs, want_mask=True)
+        sep = [eng.infer_full(img[a:b], hs[a:b], want_mask=True) for a, b in ((0, 2), (2, 4), (4, 5))]
+        eng.set_option('micro_batch', '2')
+        eng.set_profiling(1)
+        parts = eng.infer_full(img, hs, want_mask=True)
+        rows = eng.profile()
+        eng.set_profiling(0)
+    finally:
+        eng.set_option('micro_batch', 'auto')
+    assert sum(1 for r in rows if r[0] == 'mask_grow') == 3                 # chunks of 2 + 2 + 1 in ONE profile
+    for k in ('mask', 'center', 'scale', 'scoremap', 'crop', 'kpmap', 'coord3d'):
+        assert np.array_equal(np.concatenate([o[k] for o in sep], 0), parts[k]), k
+    assert np.abs(whole['scoremap'] - parts['scoremap']).max() < 2e-5
+    iou = (np.logical_and(whole['mask'] > 0, parts['mask'] > 0).sum() + 1.0) / (np.logical_or(whole['mask'] > 0, parts['mask'] > 0).sum() + 1.0)
+    assert iou > 0.999
+    with pytest.raises(AssertionError):
+        eng.set_option('micro_batch', 'many')

@@ -94,3 +94,9 @@ def test_timing_and_comm_entry_points_on_interpreter(emu_engine, synth_weights):
         emu_engine.bcast_weights(0)
     with pytest.raises(AssertionError):
         emu_engine.comm_init(0, 1, b'short')
+    emu_engine.set_option('micro_batch', '0')
+    emu_engine.set_option('micro_batch', '32')
+    emu_engine.set_option('micro_batch', 'auto')
+    for bad in ('-1', 'x', '3.5', ''):
+        with pytest.raises(AssertionError):
+            emu_engine.set_option('micro_batch', bad)

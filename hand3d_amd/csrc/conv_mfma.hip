@@ -401,7 +401,6 @@ int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
     return -1;
 }
 
-const int kCfgTH[6] = {8, 8, 8, 8, 8, 8};
 const int kCfgTW[6] = {16, 16, 16, 8, 8, 8};
 const int kCfgBN[6] = {128, 64, 32, 128, 64, 32};
 

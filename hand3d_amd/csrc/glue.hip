@@ -57,27 +57,6 @@ void conv_splitk_reduce_kernel(const float* partial, int ksplit, long npix, int 
 }
 
 // ---------------------------------------------------------------------------------------
-// im2col3x3: image [B,H,W,3] -> [B,H,W,32] with channel (r*3+s)*3+c = img[y+r-1][x+s-1][c]
-// (zero outside, channels 27..31 zero).  conv1_1 (Cin=3) then runs as a 1x1 MFMA conv with K=32.
-HP3D_KERNEL(256)
-void im2col3x3_kernel(const float* img, int B, int H, int W, float* out) {
-    const long total = (long)B * H * W * 32;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int kk = (int)(i & 31);
-        long r = i >> 5;
-        const int x = (int)(r % W); r /= W;
-        const int y = (int)(r % H);
-        const int b = (int)(r / H);
-        float v = 0.f;
-        if (kk < 27) {
-            const int tap = kk / 3, c = kk - tap * 3;
-            const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = img[(((size_t)b * H + iy) * W + ix) * 3 + c];
-        }
-        out[i] = v;
-    }
-}
-
 // 2x2/2 VALID max-pool (utils/general.py:61-65), standalone (the pipeline uses the fused epilogue)
 HP3D_KERNEL(256)
 void maxpool2_kernel(const float* x, int B, int H, int W, int C, int in_cs, float* out) {
@@ -626,9 +605,6 @@ void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int 
                                float* out, int out_cs, int cout_store, hipStream_t s) {
     HP3D_LAUNCH(conv_splitk_reduce_kernel, dim3(grid_for(npix * cout_store)), dim3(256), 0, s, partial, ksplit, npix,
                 Cout, bias, act, out, out_cs, cout_store);
-}
-void im2col3x3_launch(const float* img, int B, int H, int W, float* out32, hipStream_t s) {
-    HP3D_LAUNCH(im2col3x3_kernel, dim3(grid_for((long)B * H * W * 32)), dim3(256), 0, s, img, B, H, W, out32);
 }
 void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, float* out, hipStream_t s) {
     HP3D_LAUNCH(maxpool2_kernel, dim3(grid_for((long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, s, x, B, H, W, C,

@@ -60,9 +60,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 #else
 typedef int hp3d_rsrc_t;
 #define HP3D_MAKE_RSRC(ptr, bytes) 0
-#define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc))
-#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) (f32x4{0.f, 0.f, 0.f, 0.f})
-#define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc))
+#define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
+#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
+#define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #endif
 #endif
 
@@ -116,7 +116,6 @@ void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, 
                        const float* bias, int k, int stride, int Cout, int act, float* out, int out_cs,
                        int Ho, int Wo, int pad_t, int pad_l, hipStream_t s);
 
-void im2col3x3_launch(const float* img, int B, int H, int W, float* out32, hipStream_t s);
 void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, float* out, hipStream_t s);
 void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int out_cs, hipStream_t s);
 void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs,

@@ -1,0 +1,157 @@
+"""Second, independent restatement of the three networks in torch (CPU, float64) -- written from the layer lists of
+the reference (nets/ColorHandPose3DNetwork.py:131-168 HandSegNet, :170-219 PoseNet2D, :249-334 PosePrior /
+ViewpointNet / Rodrigues) and NOT from oracle/nets.py -- to pin the oracle's composition: layer order, channel
+counts, where the pools sit, which layers have no activation, the 149-channel concat order (score map first), the
+(h, w, c) flatten order, hand-side concatenation, the right-hand flip and the row-vector rotation.  The op-level
+semantics (TF SAME padding, legacy bilinear) are pinned separately in tests/test_oracle_ops.py.
+Parity stays "unpinned" against TensorFlow itself (absent here); this removes the single-author-single-code risk."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hand3d_amd import synth
+from oracle import nets as N
+from oracle import tf_ops as T
+
+torch.set_num_threads(8)
+D = torch.float64
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(D)
+
+
+def conv_tf_same(x_nhwc, w_hwio, b, stride, act):
+    """tf.nn.conv2d(..., 'SAME') + bias (+ leaky 0.01): explicit TF padding (extra pixel at the bottom / right)."""
+    x = x_nhwc.permute(0, 3, 1, 2)
+    k = w_hwio.shape[0]
+    H, W = x.shape[2], x.shape[3]
+    oh, ow = -(-H // stride), -(-W // stride)
+    ph = max((oh - 1) * stride + k - H, 0)
+    pw = max((ow - 1) * stride + k - W, 0)
+    x = F.pad(x, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
+    y = F.conv2d(x, w_hwio.permute(3, 2, 0, 1), b, stride=stride)
+    if act:
+        y = torch.maximum(y, 0.01 * y)
+    return y.permute(0, 2, 3, 1)
+
+
+def pool2(x_nhwc):
+    return F.max_pool2d(x_nhwc.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1)
+
+
+class Net:
+    def __init__(self, weights, scope):
+        self.w, self.scope = weights, scope
+
+    def c(self, x, name, stride=1, act=True):
+        return conv_tf_same(x, _t(self.w['%s/%s/weights' % (self.scope, name)]), _t(self.w['%s/%s/biases' % (self.scope, name)]), stride, act)
+
+    def fc(self, x, name, act=True):
+        y = x @ _t(self.w['%s/%s/weights' % (self.scope, name)]) + _t(self.w['%s/%s/biases' % (self.scope, name)])
+        return torch.maximum(y, 0.01 * y) if act else y
+
+
+def handsegnet_torch(w, image):
+    n, x = Net(w, 'HandSegNet'), _t(image)
+    for blk, nconv in enumerate([2, 2, 4, 4], 1):
+        for i in range(1, nconv + 1):
+            x = n.c(x, 'conv%d_%d' % (blk, i))
+        if blk < 4:
+            x = pool2(x)
+    x = n.c(x, 'conv5_1')
+    x = n.c(x, 'conv5_2')
+    x = n.c(x, 'conv6_1')
+    return n.c(x, 'conv6_2', act=False)          # [B, H/8, W/8, 2] before the x8 upsample
+
+
+def posenet_torch(w, crop):
+    n, x = Net(w, 'PoseNet2D'), _t(crop)
+    for blk, nconv in enumerate([2, 2, 4, 2], 1):
+        for i in range(1, nconv + 1):
+            x = n.c(x, 'conv%d_%d' % (blk, i))
+        if blk < 4:
+            x = pool2(x)
+    for i in range(3, 8):
+        x = n.c(x, 'conv4_%d' % i)
+    enc = x
+    x = n.c(x, 'conv5_1')
+    sm = n.c(x, 'conv5_2', act=False)
+    outs = [sm]
+    for unit in (6, 7):
+        x = torch.cat([sm, enc], 3)               # score map FIRST
+        for i in range(1, 6):
+            x = n.c(x, 'conv%d_%d' % (unit, i))
+        x = n.c(x, 'conv%d_6' % unit)
+        sm = n.c(x, 'conv%d_7' % unit, act=False)
+        outs.append(sm)
+    return outs
+
+
+def lifting_torch(w, sm32, hand_side):
+    hs = _t(hand_side)
+    x = _t(sm32)
+    n = Net(w, 'PosePrior')
+    for i in range(3):
+        x = n.c(x, 'conv_pose_%d_1' % i)
+        x = n.c(x, 'conv_pose_%d_2' % i, stride=2)
+    x = torch.cat([x.reshape(x.shape[0], -1), hs], 1)         # NHWC flatten = (h, w, c), then hand side
+    x = n.fc(x, 'fc_rel0')
+    x = n.fc(x, 'fc_rel1')
+    can = n.fc(x, 'fc_xyz', act=False).reshape(-1, 21, 3)
+    v = Net(w, 'ViewpointNet')
+    y = _t(sm32)
+    for i in range(3):
+        y = v.c(y, 'conv_vp_%d_1' % i)
+        y = v.c(y, 'conv_vp_%d_2' % i, stride=2)
+    y = torch.cat([y.reshape(y.shape[0], -1), hs], 1)
+    y = v.fc(y, 'fc_vp0')
+    y = v.fc(y, 'fc_vp1')
+    u = torch.cat([v.fc(y, 'fc_vp_ux', act=False), v.fc(y, 'fc_vp_uy', act=False), v.fc(y, 'fc_vp_uz', act=False)], 1)
+    theta = torch.sqrt((u * u).sum(1) + 1e-8)
+    ax = u / theta[:, None]
+    st, ct = torch.sin(theta), torch.cos(theta)
+    ux, uy, uz = ax[:, 0], ax[:, 1], ax[:, 2]
+    one = 1.0 - ct
+    R = torch.stack([ct + ux * ux * one, ux * uy * one - uz * st, ux * uz * one + uy * st,
+                     uy * ux * one + uz * st, ct + uy * uy * one, uy * uz * one - ux * st,
+                     uz * ux * one - uy * st, uz * uy * one + ux * st, ct + uz * uz * one], 1).reshape(-1, 3, 3)
+    right = hs.argmax(1) == 1
+    flip = can.clone()
+    flip[right, :, 2] = -flip[right, :, 2]
+    return can, R, flip @ R                       # row vectors times R
+
+
+@pytest.fixture(scope='module')
+def weights():
+    return synth.make_weights()
+
+
+def test_handsegnet_composition(weights):
+    img = synth.make_batch(5, 1, 48, 64)
+    small = handsegnet_torch(weights, img).numpy()
+    ref_small, (ref_full,) = N.handsegnet(weights, img, acc=np.float64)
+    assert small.shape == ref_small.shape == (1, 6, 8, 2) and np.abs(small - ref_small).max() < 1e-5
+    assert ref_full.shape == (1, 48, 64, 2)
+
+
+def test_posenet_composition(weights):
+    crop = synth.make_batch(6, 1, 64, 64)
+    outs = posenet_torch(weights, crop)
+    refs = N.posenet2d(weights, crop, acc=np.float64)
+    assert len(outs) == len(refs) == 3
+    for a, b in zip(outs, refs):
+        assert a.shape == b.shape and np.abs(a.numpy() - b).max() < 1e-5
+
+
+def test_lifting_composition(weights):
+    rng = np.random.default_rng(3)
+    sm = (rng.standard_normal((4, 32, 32, 21)) * 0.3).astype(np.float32)
+    hs = synth.hand_sides(4)
+    assert hs.argmax(1).tolist().count(1) >= 1 and hs.argmax(1).tolist().count(0) >= 1        # both hands present
+    can, R, coord = lifting_torch(weights, sm, hs)
+    rel, rcan, rR = N.pose3d(weights, sm, hs, acc=np.float64)
+    assert np.abs(can.numpy() - rcan).max() < 1e-5
+    assert np.abs(R.numpy() - rR).max() < 1e-5
+    assert np.abs(coord.numpy() - rel).max() < 1e-5

@@ -64,6 +64,7 @@ _SIGNATURES = {
     'hp3d_bcast_weights': (C.c_int, [_ctx, C.c_int]),
     'hp3d_allgather': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'hp3d_comm_destroy': (C.c_int, [_ctx]),
+    'hp3d_crc32c': (C.c_uint32, [C.c_void_p, C.c_size_t]),
 }
 COMM_ID_BYTES = 128
 TIMING_STAGES = ('HandSegNet', 'mask_crop', 'PoseNet2D', 'lifting', 'total')

@@ -1549,4 +1549,31 @@ int hp3d_allgather(hp3d_ctx* ctx, const float*, int, float*) { HP3D_FAIL(ctx, HP
 int hp3d_comm_destroy(hp3d_ctx*) { return 0; }
 #endif
 
+uint32_t hp3d_crc32c(const void* data, size_t n) {
+    static uint32_t T[8][256];
+    static bool init = false;
+    if (!init) {
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+            T[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; ++i)
+            for (int t = 1; t < 8; ++t) T[t][i] = (T[t - 1][i] >> 8) ^ T[0][T[t - 1][i] & 0xFF];
+        init = true;
+    }
+    const unsigned char* p = (const unsigned char*)data;
+    uint32_t crc = 0xFFFFFFFFu;
+    while (n >= 8) {                       // slicing-by-8
+        uint32_t lo, hi;
+        memcpy(&lo, p, 4); memcpy(&hi, p + 4, 4);
+        lo ^= crc;
+        crc = T[7][lo & 0xFF] ^ T[6][(lo >> 8) & 0xFF] ^ T[5][(lo >> 16) & 0xFF] ^ T[4][lo >> 24] ^
+              T[3][hi & 0xFF] ^ T[2][(hi >> 8) & 0xFF] ^ T[1][(hi >> 16) & 0xFF] ^ T[0][hi >> 24];
+        p += 8; n -= 8;
+    }
+    while (n--) crc = T[0][(crc ^ *p++) & 0xFF] ^ (crc >> 8);
+    return crc ^ 0xFFFFFFFFu;
+}
+
 }  // extern "C"

@@ -183,6 +183,11 @@ int hp3d_bcast_weights(hp3d_ctx* ctx, int root);
 int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv_host /* [nranks * count] */);
 int hp3d_comm_destroy(hp3d_ctx* ctx);
 
+/* ---- host utility ----------------------------------------------------------------------------
+ * CRC-32C (Castagnoli) of a host buffer: the checksum TensorFlow checkpoints carry (hand3d_amd/utils/tf_checkpoint.py
+ * verifies 140 MB of tensors with it; the pure-Python loop manages ~5 MB/s).  No device involved.          */
+uint32_t hp3d_crc32c(const void* data, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

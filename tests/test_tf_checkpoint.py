@@ -1,0 +1,81 @@
+"""TF V2 checkpoint reader + load_weights_from_snapshot selection semantics
+(reference utils/general.py:614-651).  No TensorFlow here: the format code is exercised by round trips, corruption
+checks and the published crc32c test vectors."""
+import numpy as np
+import pytest
+
+from hand3d_amd.utils import tf_checkpoint as C
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 B.4 test vectors for CRC32C (Castagnoli)
+    assert C.crc32c(b'') == 0
+    assert C.crc32c(bytes(32)) == 0x8A9136AA
+    assert C.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert C.crc32c(bytes(range(32))) == 0x46DD794E
+    assert C.crc32c(b'123456789') == 0xE3069283
+    # the engine library's slicing-by-8 version agrees with the table loop (odd lengths, unaligned tails)
+    rng = np.random.default_rng(1)
+    for n in (65, 100, 1023, 4099):
+        b = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert C.crc32c(b) == C.crc32c(b, force_python=True)
+
+
+def test_bundle_round_trip_and_selection(tmp_path):
+    rng = np.random.default_rng(0)
+    tensors = {'global_step': np.array(1234, np.int64), 'beta1_power': np.array(0.9, np.float32)}
+    for i in range(40):                                   # > one table block, shared key prefixes
+        base = 'PoseNet2D/conv%d_%d' % (i // 8 + 1, i % 8 + 1)
+        tensors[base + '/weights'] = rng.standard_normal((3, 3, 4, 5)).astype(np.float32)
+        tensors[base + '/biases'] = rng.standard_normal(5).astype(np.float32)
+        tensors[base + '/weights/Adam'] = np.zeros((3, 3, 4, 5), np.float32)
+        tensors[base + '/weights/Adam_1'] = np.zeros((3, 3, 4, 5), np.float32)
+    tensors['CPM/PoseNet/conv1_1/weights'] = rng.standard_normal((3, 3, 3, 8)).astype(np.float32)
+    tensors['half'] = rng.standard_normal((2, 3)).astype(np.float16)
+    tensors['empty'] = np.zeros((0, 4), np.float32)
+    prefix = C.write_bundle(str(tmp_path / 'model-30000'), tensors)
+    back = C.read_bundle(prefix)
+    assert set(back) == set(tensors)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    # eval2d.py:70 / eval3d.py:74 selection
+    sel = C.load_weights_from_snapshot(prefix, discard_list=['Adam', 'global_step', 'beta'])
+    assert 'global_step' not in sel and 'beta1_power' not in sel and not any('Adam' in k for k in sel)
+    assert len(sel) == 80 + 3
+    # training_posenet.py:74-76 style rename
+    ren = C.load_weights_from_snapshot(prefix, discard_list=['Adam', 'global_step', 'beta', 'PoseNet2D'],
+                                       rename_dict={'CPM/PoseNet': 'PoseNet2D'})
+    assert 'PoseNet2D/conv1_1/weights' in ren and np.array_equal(ren['PoseNet2D/conv1_1/weights'], tensors['CPM/PoseNet/conv1_1/weights'])
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = C.write_bundle(str(tmp_path / 'm'), {'a/weights': np.arange(12, dtype=np.float32).reshape(3, 4)})
+    raw = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    raw[5] ^= 0x40
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError):
+        C.read_bundle(prefix)
+    assert C.read_bundle(prefix, verify=False)['a/weights'].shape == (3, 4)
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    idx[3] ^= 0x01
+    open(prefix + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ValueError):
+        C.read_bundle(prefix)
+    open(prefix + '.index', 'wb').write(b'not a table')
+    with pytest.raises(ValueError):
+        C.read_bundle(prefix)
+
+
+def test_snapshot_feeds_the_engine_loader(tmp_path, emu_engine, synth_weights):
+    """A retrained snapshot (with optimizer slots) goes through the converter into init_from_dict."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    snap = dict(synth_weights)
+    snap['global_step'] = np.array(7, np.int64)
+    for k in list(synth_weights)[:5]:
+        snap[k + '/Adam'] = np.zeros_like(synth_weights[k])
+    prefix = C.write_bundle(str(tmp_path / 'snapshots' / 'model-1'), snap)
+    w = C.load_weights_from_snapshot(prefix, discard_list=['Adam', 'global_step', 'beta'])
+    assert set(w) == set(synth_weights)
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(w)
+    assert emu_engine.nets_mask() & 15 == 15

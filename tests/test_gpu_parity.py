@@ -549,3 +549,20 @@ def test_micro_batch_chunks_equal_separate_calls(net, synth_weights):
     assert iou > 0.999
     with pytest.raises(AssertionError):
         eng.set_option('micro_batch', 'many')
+
+
+def test_full_pipeline_odd_tile_grids_winograd(net, synth_weights):
+    """248x328: the pyramid is 124x164 -> 62x82 -> 31x41, so the Winograd layers see odd tile grids (half tiles at the
+    right / bottom edge, items that straddle images); 33 images = one chunk of 32 plus a single-image chunk."""
+    B, H, W = 33, 248, 328
+    img = synth.make_batch(5248, B, H, W)
+    hs = synth.hand_sides(B)
+    o = net.engine.infer_full(img, hs, want_mask=True)
+    for i in (5, B - 1):
+        taps = {}
+        ref = N.inference(synth_weights, img[i:i + 1], hs[i:i + 1], True, acc=np.float64, taps=taps)
+        assert np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0])
+        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2])
+        assert np.abs(o['scoremap'][i:i + 1] - ref[0]).max() < TOL_HEATMAP
+        assert np.abs(o['kpmap'][i:i + 1] - ref[4]).max() < TOL_HEATMAP
+        assert np.abs(o['coord3d'][i:i + 1] - ref[5]).max() < TOL_KP3D

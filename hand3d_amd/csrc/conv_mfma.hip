@@ -372,20 +372,16 @@ int launch_cfg(const ConvParams& p, int cfg, hipStream_t s) {
     case id: {                                                                                       \
         using C = ConvCfg<KS, STRIDE, TH, TW, WM, WN, MT, NT>;                                        \
         auto kern = conv_mfma_kernel<KS, STRIDE, TH, TW, WM, WN, MT, NT, POOL, F16>;                       \
-        static bool attr_done = false, attr_done2 = false;                                          \
-        if (!attr_done) {                                                                            \
+        static bool attr_done[64] = {}, attr_done2[64] = {};                                         \
+        if (hp3d_first_use_on_device(attr_done))                                                     \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 C::SMEM_BYTES);                                                      \
-            attr_done = true;                                                                        \
-        }                                                                                            \
         dim3 grid(p.B * p.tiles_y * p.tiles_x, p.Cout / C::BN, p.ksplit);                            \
         const ConvParams& pp = p;                                                                    \
         static int extra_lds = getenv("HP3D_CONV_EXTRA_LDS") ? atoi(getenv("HP3D_CONV_EXTRA_LDS")) : 0; \
-        if (extra_lds && !attr_done2) {                                                              \
+        if (extra_lds && hp3d_first_use_on_device(attr_done2))                                       \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 C::SMEM_BYTES + extra_lds);                                          \
-            attr_done2 = true;                                                                       \
-        }                                                                                            \
         HP3D_LAUNCH(kern, grid, dim3(C::NTHR), C::SMEM_BYTES + extra_lds, s, pp);                    \
         return 0;                                                                                    \
     }

@@ -372,14 +372,12 @@ int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, i
 template <bool POOL, int NT>
 static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
     using Cfg = WinoCfg<NT>;
-    static bool attr_done = false;
+    static bool attr_done[64] = {};
     auto k = conv_wino_kernel<POOL, NT>;
-    if (!attr_done) {
+    if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
-        attr_done = true;
-    }
     const long items = (tiles + NT - 1) / NT * (p.Cout / Cfg::COUTS);
-    static const int slots = hp3d_num_cus();              // persistent grid: one workgroup per CU
+    const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU (of the current device)
     dim3 grid((unsigned)(items < slots ? items : slots));
     HP3D_LAUNCH(k, grid, dim3(256), Cfg::SMEM_BYTES, s, p);
 }

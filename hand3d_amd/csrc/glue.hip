@@ -662,11 +662,9 @@ void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltm
                       float* crop_size, float* scale, int* seed, hipStream_t s) {
     const int WW = (W + 31) / 32;
     const size_t smem = (size_t)3 * H * WW * sizeof(unsigned);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static bool attr_done[64] = {};
+    if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)mask_grow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        attr_done = true;
-    }
     HP3D_LAUNCH(mask_grow_kernel, dim3(B), dim3(1024), smem, s, (const unsigned char*)mb.det,
                 (const unsigned long long*)mb.argmax_key, H, W, empty_fltmax, mask_out, center, crop_size, scale, seed);
 }

@@ -28,10 +28,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // keeps a per-lane value in a register as-is (the compiler may not re-derive it from other values)
 #define HP3D_OPAQUE_V(x) asm volatile("" : "+v"(x))
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-static inline int hp3d_num_cus() {
+// true the first time it is called for (this call site's flag array, current device): kernel function attributes
+// (dynamic LDS size) are per device, and one process may hold contexts on several devices
+static inline bool hp3d_first_use_on_device(bool (&done)[64]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+}
+static inline int hp3d_num_cus() {          // CUs of the current device (cached per device)
+    static int cache[64] = {};
     int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev]) return cache[dev];
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return cache[dev] = n;
 }
 // scheduling groups inside one sched-barrier region: "next, n instructions of this kind"
 #define HP3D_SG_VALU 0x2

@@ -42,6 +42,7 @@ extern EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu
 #define HP3D_KERNEL2(nthr, w)
 #define HP3D_SCHED_BARRIER() ((void)0)
 #define HP3D_OPAQUE_V(x) ((void)0)
+static inline bool hp3d_first_use_on_device(bool (&done)[64]) { const bool f = !done[0]; done[0] = true; return f; }
 static inline int hp3d_num_cus() { return 3; }     // small on purpose: persistent kernels walk several items per workgroup
 #define HP3D_SG_VALU 0x2
 #define HP3D_SG_MFMA 0x8

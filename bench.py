@@ -44,6 +44,7 @@ def parse():
                     help="f32 = exact f32 MFMA (headline); f16 = half-precision trunks, BASELINE config 5 (looser parity)")
     ap.add_argument('--comm', default='torch', choices=['torch', 'native'],
                     help="weight broadcast: torch.distributed (RCCL) or the engine's own hp3d_comm_init + hp3d_bcast_weights")
+    ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (hp3d_set_option graph=1; small batches)')
     ap.add_argument('--streams', type=int, default=1, help='engine contexts (HIP streams) per GPU; the per-GPU batch is split across them')
     return ap.parse_args()
 
@@ -114,6 +115,9 @@ def main():
         e2.blob_import(blob.data_ptr(), eng.nets_mask())
         del blob
         engines.append(e2)
+    if a.graph:
+        for e in engines:
+            e.set_option('graph', '1')
     assert B % len(engines) == 0, "--batch must be divisible by --streams"
     Bs = B // len(engines)
 

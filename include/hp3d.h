@@ -61,7 +61,10 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            allows) | "naive" (debug cross-check kernel, never a fallback);
  *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N
  *                            images ("0" = never split; default "auto" = 32 in float32 mode, no split with f16 trunks).
- *                            Bit-identical to making the calls chunk by chunk.                               */
+ *                            Bit-identical to making the calls chunk by chunk;
+ *          "graph"        = "0" | "1": the device-pointer entry points (hp3d_infer_full_dev, hp3d_posenet2d_dev) replay
+ *                            their launch sequence as one hipGraph from the third identical call on (same shape and
+ *                            pointers); meant for small batches.  Default "0".                               */
 int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value);
 
 /* ---- weights ----------------------------------------------------------------------------

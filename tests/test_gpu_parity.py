@@ -573,3 +573,75 @@ def test_full_pipeline_odd_tile_grids_winograd(net, synth_weights):
         assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2])
         assert np.abs(o['kpmap'][i:i + 1] - ref[4]).max() < TOL_HEATMAP
         assert np.abs(o['coord3d'][i:i + 1] - ref[5]).max() < TOL_KP3D
+
+
+class _DevBuf(object):
+    """device memory through the HIP runtime the engine itself links (no torch in this process)."""
+    _hip = None
+
+    def __init__(self, array_or_bytes):
+        import ctypes as C
+        if _DevBuf._hip is None:
+            _DevBuf._hip = C.CDLL('libamdhip64.so')
+        self.C, self.hip = C, _DevBuf._hip
+        self.nbytes = array_or_bytes if isinstance(array_or_bytes, int) else array_or_bytes.nbytes
+        self.ptr = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(self.ptr), C.c_size_t(self.nbytes)) == 0
+        if not isinstance(array_or_bytes, int):
+            self.upload(array_or_bytes)
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a)
+        assert self.hip.hipMemcpy(self.ptr, a.ctypes.data_as(self.C.c_void_p), self.C.c_size_t(a.nbytes), 1) == 0
+
+    def download(self, shape):
+        out = np.empty(shape, np.float32)
+        assert self.hip.hipMemcpy(out.ctypes.data_as(self.C.c_void_p), self.ptr, self.C.c_size_t(out.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        self.hip.hipFree(self.ptr)
+
+
+def test_hipgraph_replay_matches_plain_launches(net, synth_weights):
+    """hp3d_set_option("graph", "1"): from the third identical device-pointer call on the launch sequence is replayed
+    as one hipGraph -- same bytes out as the plain launches; new data behind the same pointers is picked up; a changed
+    option drops the captured graph."""
+    eng = net.engine
+    crop = _DevBuf(synth.make_batch(9100, 2, 256, 256))
+    outs = [_DevBuf(2 * 32 * 32 * 21 * 4) for _ in range(3)]
+    img = _DevBuf(synth.make_batch(9300, 1, 240, 320))
+    hs_h = synth.hand_sides(1)
+    hs = _DevBuf(hs_h)
+    coord = _DevBuf(63 * 4)
+
+    def run():
+        rc = eng.lib.hp3d_posenet2d_dev(eng.h, 2, 256, 256, crop.ptr, outs[0].ptr, outs[1].ptr, outs[2].ptr)
+        assert rc == 0, eng.lib.hp3d_last_error(eng.h)
+        eng.sync()
+        return [o.download((2, 32, 32, 21)) for o in outs]
+
+    try:
+        plain = run()
+        eng.set_option('graph', '1')
+        for g in [run() for _ in range(4)]:                  # warm-up, capture, replay, replay
+            for a, b in zip(g, plain):
+                assert np.array_equal(a, b)
+        crop.upload(synth.make_batch(9200, 2, 256, 256))      # same pointers, new data
+        eng.set_option('graph', '0')
+        plain2 = run()
+        eng.set_option('graph', '1')
+        for _ in range(3):
+            g2 = run()
+        for a, b in zip(g2, plain2):
+            assert np.array_equal(a, b)
+        assert not np.array_equal(plain2[2], plain[2])
+        ref = eng.infer_full(synth.make_batch(9300, 1, 240, 320), hs_h)['coord3d']
+        for _ in range(4):
+            eng.infer_full_dev(1, 240, 320, img.ptr.value, hs.ptr.value, coord3d=coord.ptr.value)
+            eng.sync()
+            assert np.array_equal(coord.download((1, 21, 3)), ref)
+    finally:
+        eng.set_option('graph', '0')
+        for b in [crop, img, hs, coord] + outs:
+            b.free()

@@ -172,17 +172,19 @@ def main():
         fam = {}
         for name, kern, ms, fl, by in rows:
             k = 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else kern
-            f = fam.setdefault(k, [0.0, 0.0, 0.0, 0])
-            f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1
+            # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter
+            # as nine 3x3 blocks 9*16 per 4*49
+            exe = (144.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k == 'conv_wino' else 1.0
+            f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
+            f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
         total_ms = max(sum(v[0] for v in fam.values()), 1e-9)
         peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_F16_MFMA_TFLOPS
 
         def roof_of(k):
-            ms, fl, by, n = fam[k]
+            ms, fl, by, n, fle = fam[k]
             ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            # Winograd executes 16/36 of the direct form's multiply-adds: `achieved` stays ALGORITHMIC (direct-conv
-            # FLOPs), `mfma_executed` is what the matrix cores actually ran
-            exe = ach * (16.0 / 36.0) if k == 'conv_wino' else ach
+            # `achieved` stays ALGORITHMIC (direct-conv FLOPs); `mfma_executed` is what the matrix cores ran
+            exe = fle / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "mfma_executed": round(exe, 2), "mfma_executed_frac": round(exe / peak, 4),
                     "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
@@ -193,7 +195,7 @@ def main():
         roof = roof_of(dom)
         if dom == 'conv_wino':
             roof["note"] = ("achieved = direct-form (algorithmic) FLOPs / time; the kernel is float32 Winograd F(2x2,3x3), "
-                            "which executes 16/36 of them, so frac can exceed 1; mfma_executed_frac is the matrix-core "
+                            "which executes 16/36 of them (7x7 layers as nine 3x3 blocks: 144/196), so frac can exceed 1; mfma_executed_frac is the matrix-core "
                             "utilisation against the same dense f32 peak")
         # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
         # scripts/summarize_prof.py -> profiles/<family>_traffic.json); counters cannot be read in-process.

@@ -24,7 +24,11 @@
 //     (buffer_load_dwordx4, scalar offset per (plane, step)), ring of 4 planes, 3 ahead: no LDS for B;
 //   * persistent grid (one workgroup per CU) pulling work items from a global counter; the next item's first
 //     window / weight fragments are fetched under the current item's last step;
-//   * the 2x2 outputs of a tile are one pooling window: bias + leaky-ReLU + max-pool stay a register epilogue.
+//   * the 2x2 outputs of a tile are one pooling window: bias + leaky-ReLU + max-pool stay a register epilogue;
+//   * 7x7 filters (PoseNet2D refinement units) run on the same kernel: the filter, zero-extended to 9x9, is nine 3x3
+//     blocks; block (i,j) is a 3x3 convolution of the input shifted by (3i-2, 3j-2), and all nine accumulate into
+//     the SAME 16 planes (the output transform is linear) -- a 3x3 layer with 9 x Cin virtual channels: 144 instead
+//     of 196 multiplies per 2x2 outputs, 45 steps per item.
 #include "hp3d_common.h"
 #include <cstring>
 #include <type_traits>
@@ -48,7 +52,7 @@ template <int NT> struct WinoCfg {
     static constexpr int PL_PER_BASE = NT == 32 ? 14 : 16;   // planes reachable from one ds_read base (16-bit immediate)
 };
 
-template <bool POOL, int NT>
+template <bool POOL, int NT, int NSUB>
 HP3D_KERNEL2(256, 1)
 void conv_wino_kernel(const ConvParams p) {
     using Cfg = WinoCfg<NT>;
@@ -107,10 +111,13 @@ void conv_wino_kernel(const ConvParams p) {
     const int cs4 = p.in_cs * 4;
     constexpr int OOR = (int)0x80000000;
     int wv[16];               // byte offsets of the 16 window elements (OOR: zero padding)
-    auto loader_setup = [&](int tblock, bool valid) {
-        int lb, lty, ltx;
-        tile_decode(tblock * WTILES + lt, lb, lty, ltx);
-        const int wy0 = 2 * lty - 1, wx0 = 2 * ltx - 1;                              // SAME padding 1
+    // NSUB = 1: a 3x3 filter.  NSUB = 9: a 7x7 filter as the nine 3x3 blocks of its zero-extended 9x9 form; block
+    // sub = 3i + j reads the input shifted by (3i - 2, 3j - 2), so the tile coordinates stay live through the item
+    // (cb, cty, ctx_: only the NSUB = 9 instantiation keeps them; the 3x3 kernels are short of registers as it is).
+    int cb = 0, cty = 0, ctx_ = 0;
+    auto window_offsets = [&](bool valid, int lb, int lty, int ltx, int sub) {
+        const int dy = NSUB == 1 ? 0 : 3 * (sub / 3) - 2, dx = NSUB == 1 ? 0 : 3 * (sub % 3) - 2;
+        const int wy0 = 2 * lty - 1 + dy, wx0 = 2 * ltx - 1 + dx;                    // SAME padding 1 (3 for 7x7)
         const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lc * 16;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -120,6 +127,13 @@ void conv_wino_kernel(const ConvParams p) {
                 wv[r * 4 + c] = in ? wbase + (r * p.W + c) * cs4 : OOR;
             }
     };
+    auto loader_setup = [&](int tblock, bool valid) {
+        int lb, lty, ltx;
+        tile_decode(tblock * WTILES + lt, lb, lty, ltx);
+        if (NSUB > 1) { cb = valid ? lb : p.B; cty = lty; ctx_ = ltx; }
+        window_offsets(valid, lb, lty, ltx, 0);
+    };
+    auto loader_shift = [&](int sub) { window_offsets(true, cb, cty, ctx_, sub); };
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
     const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
 
@@ -156,10 +170,13 @@ void conv_wino_kernel(const ConvParams p) {
     // packed U: [plane 16][Cin/32][Cout/32][g 4][h 2][n 32][j 4] -> the 4 fragments a wave needs for one
     // (plane, step) are 4 KB contiguous: base = one scalar offset, g = an immediate
     const int CO32 = p.Cout >> 5;
-    const int nsteps = p.Cin / WCK;
-    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(16 * p.Cin) * (unsigned)p.Cout * 4u);
+    const int nsub_rt = NSUB == 1 ? 1 : p.nsub;                     // (9; kept a run-time value on purpose: the constant-
+                                                                    //  folded form of this loop nest allocates registers much worse)
+    const int csteps = p.Cin / WCK;                                 // steps per sub-kernel
+    const int nsteps = nsub_rt * csteps;
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(16 * nsub_rt * p.Cin) * (unsigned)p.Cout * 4u);
     const int chunk_stride_b = CO32 * 4096;                         // bytes between 32-channel chunks
-    const int plane_stride_b = (p.Cin >> 5) * chunk_stride_b;       // bytes between planes
+    const int plane_stride_b = nsub_rt * (p.Cin >> 5) * chunk_stride_b;    // bytes between planes
     // a 16-channel step is one half (g = 0,1 / 2,3: 2 KB) of a 32-channel chunk
     auto soff_of = [&](int plane, int step) {
         return NT == 32 ? plane * plane_stride_b + step * chunk_stride_b
@@ -230,7 +247,11 @@ void conv_wino_kernel(const ConvParams p) {
             HP3D_OPAQUE_V(ab1);
             a_fetch(0, 0);                       // first: plane 0's MFMAs wait for exactly this
             b_fetch(3, wvoff, soff_of(3, step));
+            // (virtual) channels of the next step: sub-kernel nsub_ = (step + 1) / csteps, channel step ncs
+            const int nsub_ = (lasts || NSUB == 1) ? 0 : (step + 1) / csteps;
+            const int ncs = lasts ? 0 : (step + 1) - nsub_ * csteps;
             if (lasts) loader_setup(n_tblock, n_item < nitems);
+            else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
 #pragma unroll
             for (int pl = 0; pl < 16; ++pl) {           // fully unrolled: accumulator and ring indices are static
                 HP3D_SCHED_BARRIER();
@@ -245,7 +266,7 @@ void conv_wino_kernel(const ConvParams p) {
                 for (int gj = 1; gj < 4 * G; ++gj)
                     M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
                 if (pl == 0) {               // the window loads are issued between plane 0's MFMAs, not in front of them
-                    window_fetch(lasts ? 0 : (step + 1) * (WCK * 4));
+                    window_fetch(ncs * (WCK * 4));
                     HP3D_SCHED_GROUP(HP3D_SG_DS_READ, G);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -336,32 +357,49 @@ void conv_wino_kernel(const ConvParams p) {
 
 }  // namespace
 
-// U = G g G^T per (cin, cout), packed for the kernel: [plane][chunk][Cout/32][g][h][n][j] with channel
-// 32*chunk + 8*g + 4*h + j and cout 32*co32 + n (zero padded to cin_pad x cout_pad)
-void wino_pack_weights(const float* g_hwio /*[3][3][Cin][Cout]*/, int Cin, int Cout, int cin_pad, int cout_pad, float* dst) {
+// U = G g G^T per (virtual cin, cout), packed for the kernel: [plane][chunk][Cout/32][g][h][n][j] with virtual channel
+// 32*chunk + 8*g + 4*h + j and cout 32*co32 + n (zero padded).  k = 3: virtual channel = engine channel e.  k = 7: nine
+// 3x3 blocks (i,j) of the filter zero-extended to 9x9, virtual channel = (3i + j) * cin_pad + e.  chan_map[e] = reference
+// channel of engine channel e (-1: padding); NULL = identity.
+size_t wino_packed_floats(int k, int cin_pad, int cout_pad) { return (size_t)16 * (k == 7 ? 9 : 1) * cin_pad * cout_pad; }
+
+void wino_pack_weights(const float* g_hwio /*[k][k][Cin][Cout]*/, int k, int Cin, int Cout, int cin_pad, int cout_pad,
+                       const int* chan_map, float* dst) {
     const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    const int nch = cin_pad / 32, CO32 = cout_pad / 32;
-    memset(dst, 0, sizeof(float) * (size_t)16 * cin_pad * cout_pad);
-    for (int a = 0; a < 4; ++a)
-        for (int b = 0; b < 4; ++b)
-            for (int ci = 0; ci < Cin; ++ci) {
-                const int chunk = ci >> 5, g = (ci >> 3) & 3, h = (ci >> 2) & 1, j = ci & 3;
-                for (int co = 0; co < Cout; ++co) {
-                    float s = 0.f;
-                    for (int r = 0; r < 3; ++r)
-                        for (int c = 0; c < 3; ++c) s += G[a][r] * g_hwio[((size_t)(r * 3 + c) * Cin + ci) * Cout + co] * G[b][c];
-                    dst[(((((size_t)(a * 4 + b) * nch + chunk) * CO32 + (co >> 5)) * 4 + g) * 2 + h) * 128 + (co & 31) * 4 + j] = s;
-                }
+    const int nsub = k == 7 ? 9 : 1;
+    const int nch = nsub * cin_pad / 32, CO32 = cout_pad / 32;
+    memset(dst, 0, sizeof(float) * wino_packed_floats(k, cin_pad, cout_pad));
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int u0 = k == 7 ? 3 * (sub / 3) : 0, v0 = k == 7 ? 3 * (sub % 3) : 0;
+        for (int e = 0; e < cin_pad; ++e) {
+            const int rc = chan_map ? chan_map[e] : (e < Cin ? e : -1);
+            if (rc < 0) continue;
+            const int vc = sub * cin_pad + e;
+            const int chunk = vc >> 5, g = (vc >> 3) & 3, h = (vc >> 2) & 1, j = vc & 3;
+            for (int co = 0; co < Cout; ++co) {
+                float w3[3][3];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        w3[r][c] = (u0 + r < k && v0 + c < k) ? g_hwio[((size_t)((u0 + r) * k + (v0 + c)) * Cin + rc) * Cout + co] : 0.f;
+                for (int a = 0; a < 4; ++a)
+                    for (int b = 0; b < 4; ++b) {
+                        float s = 0.f;
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c) s += G[a][r] * w3[r][c] * G[b][c];
+                        dst[(((((size_t)(a * 4 + b) * nch + chunk) * CO32 + (co >> 5)) * 4 + g) * 2 + h) * 128 + (co & 31) * 4 + j] = s;
+                    }
             }
+        }
+    }
 }
 
 // mode 1 (auto): only when the grid fills the chip (small problems stay on the direct kernel's small-batch
 // plan); mode 2 (forced, tests): whenever the shape allows.  Returns the tile count of the item shape (32: Cout %
 // 128 == 0, 64: Cout % 64 == 0) or 0.
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B) {
-    if (mode == 0 || k != 3 || stride != 1 || Cin % 32) return 0;
+    if (mode == 0 || (k != 3 && k != 7) || stride != 1 || Cin % 32) return 0;
     const int nt = Cout % 128 == 0 ? 32 : Cout % 64 == 0 ? 64 : 0;
-    if (!nt || (nt == 32 && Cin % 64)) return 0;              // at least two steps per item
+    if (!nt || (k == 3 && nt == 32 && Cin % 64)) return 0;    // at least two steps per item (a 7x7 filter has 9 x Cin/32)
     // the kernel addresses both tensors with 32-bit offsets (channel strides up to 2x the channel count)
     if ((long)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 8 >= (1L << 31)) return 0;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
@@ -369,11 +407,11 @@ int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, i
     return (mode == 2 || items >= 256) ? nt : 0;
 }
 
-template <bool POOL, int NT>
+template <bool POOL, int NT, int NSUB>
 static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
     using Cfg = WinoCfg<NT>;
     static bool attr_done[64] = {};
-    auto k = conv_wino_kernel<POOL, NT>;
+    auto k = conv_wino_kernel<POOL, NT, NSUB>;
     if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
     const long items = (tiles + NT - 1) / NT * (p.Cout / Cfg::COUTS);
@@ -385,17 +423,19 @@ static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
 int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
     // 32-bit byte / element offsets inside the kernel (buffer loads, the tile table)
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
-    if (!pin.sched) return -1;
+    if (!pin.sched || (pin.nsub != 1 && pin.nsub != 9)) return -1;
     ConvParams p = pin;
     p.tiles_x = (p.Wo + 1) / 2;          // Winograd tiles per row / column
     p.tiles_y = (p.Ho + 1) / 2;
     const long tiles = (long)p.B * p.tiles_x * p.tiles_y;
-    if (p.Cout % 128 == 0) {
-        if (pool) wino_launch_t<true, 32>(p, tiles, s); else wino_launch_t<false, 32>(p, tiles, s);
-    } else if (p.Cout % 64 == 0) {
-        if (pool) wino_launch_t<true, 64>(p, tiles, s); else wino_launch_t<false, 64>(p, tiles, s);
+    const int nt = p.Cout % 128 == 0 ? 32 : p.Cout % 64 == 0 ? 64 : 0;
+    if (!nt || (pool && p.nsub != 1)) return -1;
+    if (p.nsub == 9) {
+        if (nt == 32) wino_launch_t<false, 32, 9>(p, tiles, s); else wino_launch_t<false, 64, 9>(p, tiles, s);
+    } else if (nt == 32) {
+        if (pool) wino_launch_t<true, 32, 1>(p, tiles, s); else wino_launch_t<false, 32, 1>(p, tiles, s);
     } else {
-        return -1;
+        if (pool) wino_launch_t<true, 64, 1>(p, tiles, s); else wino_launch_t<false, 64, 1>(p, tiles, s);
     }
     return 0;
 }

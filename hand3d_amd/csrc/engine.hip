@@ -80,9 +80,10 @@ struct Tables {
         blob_floats += (size_t)l.ek * l.ek * l.cin_pad * l.cout_pad;
         l.b_off = blob_floats;
         blob_floats += l.cout_pad;
-        if (k == 3 && stride == 1 && l.mode == 0 && cout % 64 == 0) {      // Winograd F(2x2,3x3) copy (16 planes)
+        // Winograd F(2x2,3x3) copy (16 planes; a 7x7 filter as nine 3x3 blocks along the channel axis)
+        if (stride == 1 && cout % 64 == 0 && ((k == 3 && l.mode == 0) || (k == 7 && (l.mode == 0 || l.mode == 2)))) {
             l.ww_off = blob_floats;
-            blob_floats += (size_t)16 * l.cin_pad * l.cout_pad;
+            blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
         }
         if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
             l.cin_pad16 = (l.mode == 1) ? 64 : (l.mode == 2) ? 192 : (cin + 63) / 64 * 64;
@@ -441,7 +442,8 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
         p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
-        ProfScope ps(ctx, l.name, pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
+        p.nsub = l.k == 7 ? 9 : 1;
+        ProfScope ps(ctx, l.name, l.k == 7 ? "conv_wino_f2x2_3x3_as7x7" : pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
@@ -1039,8 +1041,15 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
         const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, l.name + "/biases", &b) == 0;
         mark(l.net, ok);
         if (ok) pack_conv(l, w->data.data(), b->data.data(), host.data());
-        if (ok && l.ww_off)        // U = G g G^T in the Winograd kernel's fragment order
-            wino_pack_weights(w->data.data(), l.cin, l.cout, l.cin_pad, l.cout_pad, host.data() + l.ww_off);
+        if (ok && l.ww_off) {      // U = G g G^T in the Winograd kernel's fragment order
+            std::vector<int> cmap(l.cin_pad, -1);
+            for (int e = 0; e < l.cin_pad; ++e) {
+                if (l.mode == 0) cmap[e] = e < l.cin ? e : -1;
+                else if (e < 128) cmap[e] = 21 + e;            // concat buffer [encoding | scoremap | 0] vs reference [scoremap, encoding]
+                else if (e < 149) cmap[e] = e - 128;
+            }
+            wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww_off);
+        }
     }
     for (const FcL& l : ctx->T.fc) {
         if (l.name == "ViewpointNet/fc_vp_u") {
@@ -1283,7 +1292,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     l.name = "op/conv2d";
     l.k = k; l.cin = Cin; l.cout = Cout; l.stride = stride; l.relu = act; l.net = 0;
     l.mode = 0; l.ek = k; l.cin_pad = pad32(Cin); l.cout_pad = pad32(Cout);
-    if (ctx->use_wino == 2 && !ctx->conv_naive && k == 3 && stride == 1) {       // conv_impl=winograd: no silent fallback
+    if (ctx->use_wino == 2 && !ctx->conv_naive && (k == 3 || k == 7) && stride == 1) {       // conv_impl=winograd: no silent fallback
         l.cin_pad = (Cin + 63) / 64 * 64;
         if (Cout % 64) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_impl=winograd needs Cout %% 64 == 0 (got %d)", Cout);
     }
@@ -1303,9 +1312,9 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
     if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B) && Cout % 64 == 0) {
-        const size_t wn = (size_t)16 * l.cin_pad * l.cout_pad;
+        const size_t wn = wino_packed_floats(k, l.cin_pad, l.cout_pad);
         std::vector<float> pw(wn + l.cout_pad, 0.f);
-        wino_pack_weights(w_hwio, Cin, Cout, l.cin_pad, l.cout_pad, pw.data());
+        wino_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
         for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
         float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
         ConvParams p;
@@ -1315,6 +1324,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
         p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
+        p.nsub = k == 7 ? 9 : 1;
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");

@@ -102,6 +102,7 @@ struct ConvParams {
     int f16;              // 1: half-precision operands (channel counts/strides above are in 4-byte units = f16 pairs)
     int out_f32;          // f16 mode only: store float32 (score-map heads) instead of halves
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
+    int nsub;             // conv_wino: 1 = 3x3 filter; 9 = 7x7 filter as 3x3 blocks of its zero-extended 9x9 form
     int* sched;           // conv_wino: {next-item counter, finished-workgroup counter}, both 0 between launches
 };
 
@@ -119,8 +120,9 @@ int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const Con
 const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan);
 
 // Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
-void wino_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, float* dst);
+void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B);
+size_t wino_packed_floats(int k, int cin_pad, int cout_pad);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
 // debug cross-check (one thread per output element, obviously-correct loops)

@@ -172,3 +172,23 @@ def test_winograd_kernel_on_interpreter(emu_engine, case):
     finally:
         emu_engine.set_option('conv_impl', 'mfma')
     assert np.abs(y - r).max() < 1e-5
+
+
+@pytest.mark.parametrize("case", [(1, 12, 14, 32, 128, 0), (2, 9, 11, 40, 64, 1)], ids=lambda c: "B%d_%dx%d_%d-%d_a%d" % c)
+def test_winograd_7x7_as_3x3_blocks_on_interpreter(emu_engine, case):
+    """7x7 filter on conv_wino.hip: nine 3x3 blocks of the zero-extended 9x9 filter accumulate into the same planes
+    (shifted windows, padding 3, both item shapes)."""
+    B, H, W, Cin, Cout, act = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    emu_engine.set_option('conv_impl', 'winograd')
+    try:
+        y = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+    finally:
+        emu_engine.set_option('conv_impl', 'mfma')
+    assert np.abs(y - r).max() < 1e-5

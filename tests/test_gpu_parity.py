@@ -645,3 +645,23 @@ def test_hipgraph_replay_matches_plain_launches(net, synth_weights):
         eng.set_option('graph', '0')
         for b in [crop, img, hs, coord] + outs:
             b.free()
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 160, 128), (8, 32, 32, 128, 128), (1, 20, 28, 64, 64), (33, 32, 32, 149, 128)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d" % c)
+def test_conv7x7_on_winograd_kernel_vs_oracle(gpu_engine, case):
+    """7x7 filters (PoseNet2D refinement units, nets/ColorHandPose3DNetwork.py:211-214) on conv_wino.hip: nine 3x3
+    blocks of the zero-extended 9x9 filter, shifted windows, SAME padding 3; (33, 32x32, 149 -> 128) walks more items
+    than CUs with the real layer's channel count."""
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    gpu_engine.set_option('conv_impl', 'winograd')
+    try:
+        y = gpu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+    assert np.abs(y - r).max() < 5e-5

@@ -1,7 +1,7 @@
 """Batch sharding across the GPUs of one node: every image is independent, so
 the path shards with NO data-path collective.  torch.distributed (backend "nccl" == RCCL over
 xGMI; "gloo" in the CPU tests) is used as plumbing for two tiny exchanges only:
-  * once: broadcast of the packed weight blob (140 MB f32) from rank 0;
+  * once: broadcast of the packed weight blob (468 MB: direct + Winograd-domain filters + f16 section) from rank 0;
   * per batch: gather of the [B/n,21,3] keypoints (252 B/image).
 The reference has no counterpart (single tf.Session everywhere, run.py:50).
 """

@@ -84,6 +84,17 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     ref = N.posenet2d(synth_weights, crop, acc=np.float64)
     for a, b in zip(sms, ref):
         assert a.shape == b.shape and np.abs(a - b).max() < 1e-5
+    # the same two nets with every eligible layer forced onto conv_wino.hip: 3x3 layers in both item shapes, the 7x7
+    # refinement units as nine 3x3 blocks including the concat-channel permutation of conv6_1 / conv7_1
+    emu_engine.set_option('conv_impl', 'winograd')
+    try:
+        _, small_w = emu_engine.handsegnet(img, want_small=True)
+        sms_w = net.inference_pose2d(crop)
+    finally:
+        emu_engine.set_option('conv_impl', 'mfma')
+    assert np.abs(small_w - rs).max() < 1e-5
+    for a, b in zip(sms_w, ref):
+        assert np.abs(a - b).max() < 1e-5
     rng = np.random.default_rng(5)
     sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
     hs = synth.hand_sides(2)

@@ -22,7 +22,7 @@
 //     registers), transforms them under the last planes and writes the other buffer: ONE barrier per step;
 //   * transformed weights U[plane][Cin][Cout] are pre-packed in fragment order and go global -> VGPR directly
 //     (buffer_load_dwordx4, scalar offset per (plane, step)), ring of 4 planes, 3 ahead: no LDS for B;
-//   * persistent grid (one workgroup per CU) pulling work items from a global counter; the next item's first
+//   * persistent grid (one workgroup per CU) walking work items blockIdx.x, +gridDim.x, ...; the next item's first
 //     window / weight fragments are fetched under the current item's last step;
 //   * the 2x2 outputs of a tile are one pooling window: bias + leaky-ReLU + max-pool stay a register epilogue;
 //   * 7x7 filters (PoseNet2D refinement units) run on the same kernel: the filter, zero-extended to 9x9, is nine 3x3
@@ -48,7 +48,7 @@ template <int NT> struct WinoCfg {
     static constexpr int COUTS = NT == 32 ? 128 : 64;        // output channels per item
     static constexpr int PLANE_FLOATS = NT * LDA;            // one plane of one buffer
     static constexpr int VBUF_FLOATS = 16 * PLANE_FLOATS;    // 73728 B / 65536 B
-    static constexpr int SMEM_BYTES = 2 * VBUF_FLOATS * 4 + 2 * 2 * NT * 4 + 16;     // 2 V buffers + two tile tables + next-item slot
+    static constexpr int SMEM_BYTES = 2 * VBUF_FLOATS * 4 + 2 * 2 * NT * 4;     // 2 V buffers + two tile tables
     static constexpr int PL_PER_BASE = NT == 32 ? 14 : 16;   // planes reachable from one ds_read base (16-bit immediate)
 };
 
@@ -60,9 +60,7 @@ void conv_wino_kernel(const ConvParams p) {
     constexpr int NQ = Cfg::NQ, G = Cfg::G, COUTS = Cfg::COUTS;
     HP3D_DYN_SMEM(V);
     // tile tables, double buffered by item parity: [0..NT-1] output offset of tile t (-1: no such tile), [NT..2NT-1] edge flags;
-    // then one slot for the next item's number
     int* tinfo = (int*)(V + 2 * VBUF_FLOATS);
-    int* next_slot = tinfo + 4 * WTILES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -225,8 +223,8 @@ void conv_wino_kernel(const ConvParams p) {
 
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff;
-        int n_item = nitems;
-        if (tid == 0) *next_slot = (int)gridDim.x + atomicAdd(p.sched, 1);      // read after the barrier that ends step 0
+        const int n_item = item + (int)gridDim.x;      // static round robin (a global work counter measured 0.5 % slower:
+                                                       // its returning atomic sits in the in-order vmcnt queue of wave 0)
         const int co = cy * COUTS + wcout * 32 + li;
         const float bias = p.bias[co];           // in flight during the item, used in the epilogue
 
@@ -287,7 +285,6 @@ void conv_wino_kernel(const ConvParams p) {
         };
         step_body(0, std::true_type{});
         {   // the next item (its tile table is written here, hidden under this item's MFMAs)
-            n_item = HP3D_READFIRSTLANE(*next_slot);
             const bool has_next = n_item < nitems;
             n_cy = has_next ? n_item / tile_blocks : cy;
             n_tblock = has_next ? n_item - n_cy * tile_blocks : tblock;
@@ -346,12 +343,6 @@ void conv_wino_kernel(const ConvParams p) {
         }
         if (n_item >= nitems) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
-    }
-    // the last workgroup to leave re-arms the counters for the next launch on this stream (every workgroup's
-    // final atomicAdd on sched[0] precedes its increment of sched[1])
-    if (tid == 0 && atomicAdd(p.sched + 1, 1) == (int)gridDim.x - 1) {
-        atomicExch(p.sched, 0);
-        atomicExch(p.sched + 1, 0);
     }
 }
 
@@ -423,7 +414,7 @@ static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
 int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
     // 32-bit byte / element offsets inside the kernel (buffer loads, the tile table)
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
-    if (!pin.sched || (pin.nsub != 1 && pin.nsub != 9)) return -1;
+    if (pin.nsub != 1 && pin.nsub != 9) return -1;
     ConvParams p = pin;
     p.tiles_x = (p.Wo + 1) / 2;          // Winograd tiles per row / column
     p.tiles_y = (p.Ho + 1) / 2;

@@ -224,7 +224,6 @@ struct hp3d_ctx {
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
           *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
           *d_pooled = nullptr, *d_fcpart = nullptr;
-    int* d_sched = nullptr;      // conv_wino work-queue counters (zero between launches)
     void* comm = nullptr;        // ncclComm_t (hp3d_comm_init)
     int comm_rank = 0, comm_size = 1;
     int* d_seed = nullptr;
@@ -441,7 +440,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = l.k == 7 ? 9 : 1;
         ProfScope ps(ctx, l.name, l.k == 7 ? "conv_wino_f2x2_3x3_as7x7" : pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
@@ -468,7 +467,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
         p.Cin = cin_units; p.in_cs = (f16 && l.mode != 1) ? in_cs / 2 : in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
-        p.f16 = f16; p.out_f32 = out_f32; p.sched = nullptr;
+        p.f16 = f16; p.out_f32 = out_f32;
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
@@ -905,12 +904,6 @@ int hp3d_create(int device, hp3d_ctx** out) {
         delete ctx;
         return HP3D_ERR_HIP;
     }
-    if (hipMalloc((void**)&ctx->d_sched, 2 * sizeof(int)) != hipSuccess || hipMemsetAsync(ctx->d_sched, 0, 2 * sizeof(int), ctx->stream) != hipSuccess) {
-        set_error(nullptr, "hp3d_create: hipMalloc failed");
-        hipStreamDestroy(ctx->stream);
-        delete ctx;
-        return HP3D_ERR_HIP;
-    }
     *out = ctx;
     return 0;
 }
@@ -931,7 +924,6 @@ int hp3d_destroy(hp3d_ctx* ctx) {
         if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
 #endif
     if (ctx->comm) hp3d_comm_destroy(ctx);
-    if (ctx->d_sched) hipFree(ctx->d_sched);
     if (ctx->d_seed) hipFree(ctx->d_seed);
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
@@ -1323,7 +1315,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.sched = ctx->d_sched;
+        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = k == 7 ? 9 : 1;
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
     } else if (ctx->conv_naive) {
@@ -1344,7 +1336,7 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + plan.tw - 1) / plan.tw; p.tiles_y = (Ho + plan.th - 1) / plan.th;
-        p.act = act; p.im2col = 0; p.f16 = 0; p.out_f32 = 0; p.sched = nullptr;
+        p.act = act; p.im2col = 0; p.f16 = 0; p.out_f32 = 0;
         p.ksplit = plan.ksplit; p.partial = d_part;
         if (conv_mfma_launch(p, k, stride, pool, plan, ctx->stream) != 0)
             HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_mfma launch failed");

@@ -103,7 +103,6 @@ struct ConvParams {
     int out_f32;          // f16 mode only: store float32 (score-map heads) instead of halves
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
     int nsub;             // conv_wino: 1 = 3x3 filter; 9 = 7x7 filter as 3x3 blocks of its zero-extended 9x9 form
-    int* sched;           // conv_wino: {next-item counter, finished-workgroup counter}, both 0 between launches
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------

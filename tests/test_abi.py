@@ -30,9 +30,12 @@ def test_library_exports_every_declared_symbol():
     assert dl.hp3d_abi_version() == 1
 
 
-def test_library_contains_gfx950_mfma_code():
+def test_library_contains_gfx950_mfma_code(tmp_path):
+    import shutil
     from hand3d_amd import _lib
-    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', _lib.DEFAULT_LIB],
+    lib = str(tmp_path / 'libhp3d.so')          # llvm-objdump --offloading drops the extracted bundles next to its input
+    shutil.copy(_lib.DEFAULT_LIB, lib)
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/llvm-objdump', '--offloading', lib],
                          capture_output=True, text=True).stdout
     assert 'gfx950' in out
 

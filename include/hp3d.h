@@ -56,9 +56,11 @@ const char* hp3d_last_error(hp3d_ctx* ctx);          /* ctx may be NULL: last gl
 void* hp3d_stream(hp3d_ctx* ctx);                    /* the hipStream_t all work is queued on */
 int hp3d_sync(hp3d_ctx* ctx);
 /* options: "empty_reduce" = "inf" | "fltmax" (oracle/general.py EMPTY_REDUCE);
- *          "conv_impl"    = "mfma" (default: direct MFMA kernel, float32 Winograd F(2x2,3x3) for the 3x3/stride-1
- *                            layers with Cin%64==0, Cout%128==0 whose grid fills the chip) | "direct" (never Winograd) | "winograd" (whenever the shape
- *                            allows) | "naive" (debug cross-check kernel, never a fallback);
+ *          "conv_impl"    = "mfma" (default: direct MFMA kernel, and float32 Winograd F(2x2,3x3) for the stride-1 3x3
+ *                            layers with Cout%64==0 and the 7x7 layers -- taken as nine 3x3 blocks -- whenever the grid
+ *                            fills the chip, >= 256 work items) | "direct" (never Winograd: bit-identical to an fmaf
+ *                            chain) | "winograd" (whenever the shape allows; per-op hp3d_conv2d then refuses other
+ *                            shapes) | "naive" (debug cross-check kernel, never a fallback);
  *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N
  *                            images ("0" = never split; default "auto" = 32 in float32 mode, no split with f16 trunks).
  *                            Bit-identical to making the calls chunk by chunk;

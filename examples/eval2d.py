@@ -13,6 +13,8 @@ if __name__ == '__main__':
     ap = parser(__doc__)
     ap.add_argument('--db', default=None)
     ap.add_argument('--gt-cropped', action='store_true')
+    ap.add_argument('--snapshots-posenet', default=None, help='directory of retrained PoseNet2D snapshots (TF checkpoints), eval2d.py:40')
+    ap.add_argument('--snapshots-handsegnet', default=None, help='directory of retrained HandSegNet snapshots, eval2d.py:41')
     a = ap.parse_args()
     from hand3d_amd.data import BinaryDbReader, binary_format as fmt
     from hand3d_amd.nets.ColorHandPose3DNetwork import ColorHandPose3DNetwork
@@ -34,9 +36,20 @@ if __name__ == '__main__':
     else:
         files = ['%s/handsegnet-rhd.pickle' % a.weights_dir, '%s/posenet-rhd-stb.pickle' % a.weights_dir]
         files_pose = files[1:]
+    retrained = None
+    if a.snapshots_posenet:          # USE_RETRAINED = True of eval2d.py:39-75: weights come from training snapshots
+        from hand3d_amd.utils.tf_checkpoint import latest_checkpoint, load_weights_from_snapshot
+        retrained = {}
+        for d in filter(None, [None if a.gt_cropped else a.snapshots_handsegnet, a.snapshots_posenet]):
+            last_cpt = latest_checkpoint(d)
+            assert last_cpt is not None, "Could not locate snapshot to load. Did you already train the network and set the path accordingly?"
+            retrained.update(load_weights_from_snapshot(last_cpt, discard_list=['Adam', 'global_step', 'beta']))
     util = EvalUtil()
     if a.gt_cropped:
-        net.init(None, weight_files=files_pose, exclude_var_list=['PosePrior', 'ViewpointNet', 'HandSegNet'])
+        if retrained is not None:
+            net.init_from_dict({k: v for k, v in retrained.items() if k.startswith('PoseNet2D')})
+        else:
+            net.init(None, weight_files=files_pose, exclude_var_list=['PosePrior', 'ViewpointNet', 'HandSegNet'])
         dataset = BinaryDbReader(mode='evaluation', shuffle=False, hand_crop=True, use_wrist_coord=False,
                                  path_to_db=a.db, engine=net.engine)                                 # eval2d_gt_cropped.py:37
         for i, data in enumerate(dataset.get()):
@@ -50,7 +63,10 @@ if __name__ == '__main__':
             cs = np.squeeze(data['crop_scale'])
             util.feed(kp_uv21_gt / cs, np.squeeze(data['keypoint_vis21']), coord_uv_pred_crop / cs)   # :79-82
     else:
-        net.init(None, weight_files=files, exclude_var_list=['PosePrior', 'ViewpointNet'])            # eval2d.py:78-79
+        if retrained is not None:
+            net.init_from_dict({k: v for k, v in retrained.items() if k.startswith(('HandSegNet', 'PoseNet2D'))})
+        else:
+            net.init(None, weight_files=files, exclude_var_list=['PosePrior', 'ViewpointNet'])        # eval2d.py:78-79
         dataset = BinaryDbReader(mode='evaluation', shuffle=False, use_wrist_coord=True, scale_to_size=True,
                                  path_to_db=a.db, engine=net.engine)                                 # eval2d.py:44
         for i, data in enumerate(dataset.get()):

@@ -242,6 +242,22 @@ def load_weights_from_snapshot(checkpoint_path, discard_list=None, rename_dict=N
     return out
 
 
+def latest_checkpoint(checkpoint_dir):
+    """tf.train.latest_checkpoint without TensorFlow: the prefix named by `model_checkpoint_path` in
+    <dir>/checkpoint (a text-format CheckpointState), or None (eval2d.py:68-69 asserts on that)."""
+    import re
+    state = os.path.join(checkpoint_dir, 'checkpoint')
+    if not os.path.exists(state):
+        return None
+    m = re.search(r'^\s*model_checkpoint_path:\s*"([^"]*)"', open(state).read(), re.M)
+    if not m:
+        return None
+    path = m.group(1)
+    if not os.path.isabs(path):
+        path = os.path.join(checkpoint_dir, path)
+    return path if os.path.exists(path + '.index') else None
+
+
 # ---- writer (tests, exporting weight dicts in the reference's snapshot format) ------------------------------
 def _build_block(items, restart_interval=16):
     buf, restarts, last = bytearray(), [], b''
@@ -300,4 +316,6 @@ def write_bundle(prefix, tensors, entries_per_block=24):
         f.write(bytes(table))
     with open(prefix + '.data-00000-of-00001', 'wb') as f:
         f.write(bytes(data))
+    with open(os.path.join(os.path.dirname(os.path.abspath(prefix)), 'checkpoint'), 'w') as f:       # CheckpointState
+        f.write('model_checkpoint_path: "%s"\nall_model_checkpoint_paths: "%s"\n' % ((os.path.basename(prefix),) * 2))
     return prefix

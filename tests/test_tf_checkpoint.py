@@ -74,6 +74,7 @@ def test_snapshot_feeds_the_engine_loader(tmp_path, emu_engine, synth_weights):
     for k in list(synth_weights)[:5]:
         snap[k + '/Adam'] = np.zeros_like(synth_weights[k])
     prefix = C.write_bundle(str(tmp_path / 'snapshots' / 'model-1'), snap)
+    assert C.latest_checkpoint(str(tmp_path / 'snapshots')) == prefix and C.latest_checkpoint(str(tmp_path)) is None
     w = C.load_weights_from_snapshot(prefix, discard_list=['Adam', 'global_step', 'beta'])
     assert set(w) == set(synth_weights)
     net = ColorHandPose3DNetwork(engine=emu_engine)

@@ -1,0 +1,111 @@
+// conv_first.hip -- conv1_1 of HandSegNet / PoseNet2D: 3x3, stride 1, SAME, Cin = 3 -> Cout = 64, bias + leaky-ReLU
+// (nets/ColorHandPose3DNetwork.py:144,183 through NetworkOps.conv_relu, utils/general.py:36-59), float32.
+//
+// The layer is store-bound (0.2 GFLOP per 13 MB of output per image), and on the general kernel it was bound by
+// something else again: 25 600 workgroups of ~8 us, each paying its own weight staging and window latency (0.43 ms at
+// 320x320, B=32 = 1.9 TB/s).  Here:
+//   * K = 27 (padded to 28): 14 k-steps of v_mfma_f32_32x32x2_f32 per 32 pixels x 32 couts;
+//   * the 28 x 64 filter matrix lives in 28 registers per lane for the whole workgroup (both 32-cout halves);
+//   * the im2col row of a pixel is never materialised: lane (pixel, k-half) gathers its 14 operands straight from the
+//     image with buffer loads (zero padding and the K tail = out-of-range offsets); the next tile's 14 loads fly under
+//     the current tile's MFMAs and stores;
+//   * no LDS, ~110 registers: four waves per SIMD hide the rest; a workgroup walks a strip of tiles.
+#include "hp3d_common.h"
+
+namespace {
+
+constexpr int FT_TH = 8, FT_TW = 16;       // tile: 8 rows x 16 pixels = 4 MFMA row blocks (one per wave)
+constexpr int FK = 14;                      // k-steps (K = 28 >= 27)
+
+HP3D_KERNEL(256)
+void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = HP3D_READFIRSTLANE(tid >> 6);
+    const int m = lane & 31, kh = lane >> 5;
+    // filter operands: k = 2 kk + kh, engine channel e = k = (r*3+s)*3 + c of the packed K=32 x 64 matrix
+    // wpk[c8][co32][h][n][j] (engine.hip:pack_conv, mode 1)
+    float bw[2][FK];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int kk = 0; kk < FK; ++kk) {
+            const int k = 2 * kk + kh;
+            bw[nb][kk] = p.wpk[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)];
+        }
+    const float bias0 = p.bias[m], bias1 = p.bias[32 + m];
+
+    const int strips = (p.tiles_x + tiles_per_wg - 1) / tiles_per_wg;
+    int sp = blockIdx.x;
+    const int strip = sp % strips; sp /= strips;
+    const int ty = sp % p.tiles_y;
+    const int b = sp / p.tiles_y;
+    const int tx0 = strip * tiles_per_wg, tx1 = min(p.tiles_x, tx0 + tiles_per_wg);
+
+    const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * 12u);
+    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)p.out_cs * 4u);
+    constexpr int OOR = (int)0x80000000;
+
+    // A operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
+    const int y = ty * FT_TH + 2 * wave + (m >> 4);
+    auto gather = [&](int tx, float (&a)[FK]) {
+        const int x = tx * FT_TW + (m & 15);
+#pragma unroll
+        for (int kk = 0; kk < FK; ++kk) {
+            const int k = 2 * kk + kh;
+            const int r = k / 9, s = (k / 3) % 3, c = k % 3;
+            const int yy = y + r - 1, xx = x + s - 1;
+            const bool ok = k < 27 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            a[kk] = HP3D_BUFFER_LOAD4(irsrc, ok ? (((b * p.H + yy) * p.W + xx) * 3 + c) * 4 : OOR, 0);
+        }
+    };
+    float a_cur[FK], a_nxt[FK];
+    gather(tx0, a_cur);
+    for (int tx = tx0; tx < tx1; ++tx) {
+        if (tx + 1 < tx1) gather(tx + 1, a_nxt);
+        f32x16 acc0, acc1;
+        {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc0 = HP3D_MFMA_32x32x2(a_cur[0], bw[0][0], zero);
+            acc1 = HP3D_MFMA_32x32x2(a_cur[0], bw[1][0], zero);
+        }
+#pragma unroll
+        for (int kk = 1; kk < FK; ++kk) {
+            acc0 = HP3D_MFMA_32x32x2(a_cur[kk], bw[0][kk], acc0);
+            acc1 = HP3D_MFMA_32x32x2(a_cur[kk], bw[1][kk], acc1);
+        }
+        // accumulator register r <-> pixel (r & 3) + 8 (r >> 2) + 4 kh of the row block, column = cout m of the half
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int pm = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int oy = ty * FT_TH + 2 * wave + (pm >> 4), ox = tx * FT_TW + (pm & 15);
+            const int base = (oy < p.H && ox < p.W) ? (((b * p.H + oy) * p.W + ox) * p.out_cs + m) * 4 : OOR;
+            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+            if (p.act) { v0 = fmaxf(v0, HP3D_LEAKY_SLOPE * v0); v1 = fmaxf(v1, HP3D_LEAKY_SLOPE * v1); }
+            HP3D_BUFFER_STORE4(orsrc, v0, base, 0);
+            HP3D_BUFFER_STORE4(orsrc, v1, base, 128);
+        }
+#pragma unroll
+        for (int kk = 0; kk < FK; ++kk) a_cur[kk] = a_nxt[kk];
+    }
+}
+
+}  // namespace
+
+// conv1_1 shape only: 3x3 / stride 1 / Cin 3 / Cout 64 / float32 in and out, tensors inside 32-bit byte offsets
+int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs) {
+    if (k != 3 || stride != 1 || Cin != 3 || Cout != 64 || out_cs < 64) return 0;
+    return (long)B * H * W * out_cs * 4 < (1L << 31);
+}
+
+int conv_first_launch(const ConvParams& pin, hipStream_t s) {
+    ConvParams p = pin;
+    p.tiles_x = (p.W + FT_TW - 1) / FT_TW;
+    p.tiles_y = (p.H + FT_TH - 1) / FT_TH;
+    // a workgroup walks a strip of tiles of one tile row: long enough to amortise the filter load and the first gather,
+    // short enough to leave >= ~4 workgroups per CU
+    int per = p.tiles_x;
+    while (per > 4 && (long)p.B * p.tiles_y * ((p.tiles_x + per - 1) / per) < 4 * hp3d_num_cus()) per = (per + 1) / 2;
+    const int strips = (p.tiles_x + per - 1) / per;
+    HP3D_LAUNCH(conv_first_kernel, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
+    return 0;
+}

@@ -239,6 +239,7 @@ struct hp3d_ctx {
     struct GraphEntry { hipGraphExec_t exec = nullptr; long epoch = -1; int calls = 0; };
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
+    int use_first = 1;         // conv1_1 on its own kernel (conv_first.hip); conv_impl=direct keeps it on the general one
     int use_graph = 0;
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
@@ -444,6 +445,16 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.nsub = l.k == 7 ? 9 : 1;
         ProfScope ps(ctx, l.name, l.k == 7 ? "conv_wino_f2x2_3x3_as7x7" : pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+    } else if (l.mode == 1 && !f16 && !pool && ctx->use_first && !ctx->conv_naive &&
+               conv_first_eligible(l.k, l.stride, l.cin, l.cout, B, H, W, out_cs)) {
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.w_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = 3; p.in_cs = 3; p.Cout = 64; p.out_cs = out_cs; p.cout_store = 64;
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 1;
+        ProfScope ps(ctx, l.name, "conv_first_3x3_c3", flops, bytes);
+        conv_first_launch(p, ctx->stream);
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
         conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
@@ -953,6 +964,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {
         ctx->conv_naive = (v == "naive");
         ctx->use_wino = (v == "direct" || v == "naive") ? 0 : (v == "winograd") ? 2 : 1;   // mfma = auto
+        ctx->use_first = (v == "direct" || v == "naive") ? 0 : 1;
         return 0;
     }
     if (k == "graph" && (v == "0" || v == "1")) {

@@ -66,6 +66,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
+// 4 B per lane from (rsrc base + per-lane voff + scalar soff); out-of-range offsets read 0
+#define HP3D_BUFFER_LOAD4(rsrc, voff, soff) \
+    __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 0))
 // 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
@@ -75,6 +78,7 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
 #endif
 #endif
 
@@ -120,6 +124,8 @@ const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& 
 
 // Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
 void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
+int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs);
+int conv_first_launch(const ConvParams& p, hipStream_t s);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B);
 size_t wino_packed_floats(int k, int cin_pad, int cout_pad);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);

@@ -65,6 +65,12 @@ static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
     return v;
 }
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
+static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
+    float v = 0.f;
+    if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy(&v, r.base + voff + soff, 4);
+    return v;
+}
+#define HP3D_BUFFER_LOAD4(rsrc, voff, soff) hp3d_emu_buffer_load4((rsrc), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }

@@ -1,5 +1,7 @@
-// conv_mfma.hip -- the hot kernel: NHWC float32 convolution as an implicit GEMM on the
-// gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, = an fmaf chain, 157 TF peak).
+// conv_mfma.hip -- the general (direct) convolution: NHWC float32 / float16 implicit GEMM on the
+// gfx950 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, = an fmaf chain, 157 TF peak).  It serves every layer
+// shape of the path; for large batches the 3x3 / 7x7 layers take conv_wino.hip and conv1_1 takes conv_first.hip
+// (engine.hip:run_conv), small batches, 1x1 / stride-2 layers, the f16 mode and conv_impl=direct stay here.
 //
 // Stands in for tf.nn.conv2d(SAME) + bias_add + leaky-ReLU (+ 2x2 max-pool) at every
 // NetworkOps.conv / conv_relu / max_pool call site of the reference

@@ -7,7 +7,7 @@ import tempfile
 
 import numpy as np
 
-from common import parser, synthetic_weight_files
+from common import parser, print_result, synthetic_rhd_db, synthetic_weight_files
 
 if __name__ == '__main__':
     ap = parser(__doc__)
@@ -24,14 +24,7 @@ if __name__ == '__main__':
     if a.synthetic:
         tmp = tempfile.mkdtemp()
         files = synthetic_weight_files(tmp)
-        rng = np.random.default_rng(0)
-        a.db = os.path.join(tmp, 'rhd_evaluation.bin')
-        with open(a.db, 'wb') as f:
-            for _ in range(a.limit or 4):
-                mask = np.zeros((320, 320), np.uint8)
-                mask[100:200, 80:220] = 5
-                f.write(fmt.pack_rhd_record(rng.integers(0, 256, (320, 320, 3), dtype=np.uint8), mask, rng.normal(0, .05, (42, 3)),
-                                            rng.uniform(90, 210, (42, 2)), np.ones(42), np.eye(3)))
+        a.db = synthetic_rhd_db(os.path.join(tmp, 'rhd_evaluation.bin'), a.limit or 4)
         files_pose = files
     else:
         files = ['%s/handsegnet-rhd.pickle' % a.weights_dir, '%s/posenet-rhd-stb.pickle' % a.weights_dir]
@@ -75,11 +68,18 @@ if __name__ == '__main__':
             keypoints_scoremap, image_crop, scale_crop, center = net.inference2d(data['image'])      # eval2d.py:58
             coord_hw_crop = detect_keypoints(np.squeeze(keypoints_scoremap))
             coord_hw = trafo_coords(coord_hw_crop, center, scale_crop, 256)
-            coord_uv = np.stack([coord_hw[:, 1], coord_hw[:, 0]], 1)                                  # eval2d.py:93-99
-            util.feed(np.squeeze(data['keypoint_uv21']) / np.squeeze(scale_crop), np.squeeze(data['keypoint_vis21']),
-                      coord_uv / np.squeeze(scale_crop))
+            coord_uv = np.stack([coord_hw[:, 1], coord_hw[:, 0]], 1)                                  # eval2d.py:93-95
+            # eval2d.py:52-54,97-99: the reader already delivers 240x320 frames and keypoints (scale_to_size), so the
+            # "scale to the dataset's image size" factors are 240/240 and 320/320
+            s = data['image'].shape
+            coord_uv[:, 1] /= 240.0 / s[1]
+            coord_uv[:, 0] /= 320.0 / s[2]
+            scale2orig_res = getattr(dataset, 'resolution', 1.0)                                     # eval2d.py:101-105
+            util.feed(np.squeeze(data['keypoint_uv21']) / scale2orig_res, np.squeeze(data['keypoint_vis21']),
+                      coord_uv / scale2orig_res)
     mean, median, auc, _, _ = util.get_measures(0.0, 30.0, 20)                                        # eval2d.py:112
     print('Evaluation results:')
     print('Average mean EPE: %.3f pixels' % mean)
     print('Average median EPE: %.3f pixels' % median)
     print('Area under curve: %.3f' % auc)
+    print_result(mean, median, auc)

@@ -5,7 +5,7 @@ import tempfile
 
 import numpy as np
 
-from common import parser
+from common import parser, print_result, synthetic_rhd_db
 
 if __name__ == '__main__':
     ap = parser(__doc__)
@@ -23,14 +23,7 @@ if __name__ == '__main__':
         tmp = tempfile.mkdtemp()
         w = synth.make_weights(bottleneck=(a.variant == 'bottleneck'))
         files = synth.write_weight_files(tmp, {k: v for k, v in w.items() if not k.startswith(('HandSegNet', 'PoseNet2D'))})[1:]
-        rng = np.random.default_rng(0)
-        a.db = os.path.join(tmp, 'rhd_evaluation.bin')
-        with open(a.db, 'wb') as f:
-            for _ in range(a.limit or 4):
-                mask = np.zeros((320, 320), np.uint8)
-                mask[100:200, 80:220] = 5
-                f.write(fmt.pack_rhd_record(rng.integers(0, 256, (320, 320, 3), dtype=np.uint8), mask, rng.normal(0, .05, (42, 3)),
-                                            rng.uniform(90, 210, (42, 2)), np.ones(42), np.eye(3)))
+        a.db = synthetic_rhd_db(os.path.join(tmp, 'rhd_evaluation.bin'), a.limit or 4)
     else:
         files = ['%s/lifting-%s.pickle' % (a.weights_dir, a.variant)]                                  # :76
     net.init(None, weight_files=files)
@@ -50,3 +43,4 @@ if __name__ == '__main__':
     print('Average mean EPE: %.3f mm' % (mean * 1000))
     print('Average median EPE: %.3f mm' % (median * 1000))
     print('Area under curve: %.3f' % auc)
+    print_result(mean, median, auc)

@@ -6,7 +6,7 @@ import tempfile
 
 import numpy as np
 
-from common import parser, synthetic_weight_files
+from common import parser, print_result, synthetic_stb_db, synthetic_weight_files
 
 if __name__ == '__main__':
     ap = parser(__doc__)
@@ -20,12 +20,7 @@ if __name__ == '__main__':
     if a.synthetic:
         tmp = tempfile.mkdtemp()
         files = synthetic_weight_files(tmp)
-        rng = np.random.default_rng(0)
-        a.db = os.path.join(tmp, 'stb_eval.bin')
-        with open(a.db, 'wb') as f:
-            for _ in range(a.limit or 4):
-                uvv = np.concatenate([rng.uniform(100, 400, (21, 2)), np.ones((21, 1))], 1)
-                f.write(fmt.pack_stb_record(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8), rng.normal(0, 40, (21, 3)), uvv))
+        a.db = synthetic_stb_db(os.path.join(tmp, 'stb_eval.bin'), a.limit or 4)
     else:
         files = ['%s/handsegnet-rhd.pickle' % a.weights_dir, '%s/posenet3d-rhd-stb.pickle' % a.weights_dir]   # :66-67
     net.init(None, weight_files=files)
@@ -47,3 +42,4 @@ if __name__ == '__main__':
     print('Average mean EPE: %.3f mm' % (mean * 1000))
     print('Average median EPE: %.3f mm' % (median * 1000))
     print('Area under curve between 0mm - 50mm: %.3f' % auc)
+    print_result(mean, median, auc)

@@ -77,3 +77,29 @@ def hand_sides(B):
     hs = np.zeros((B, 2), dtype=np.float32)
     hs[np.arange(B), np.arange(B) % 2] = 1.0
     return hs
+
+
+MASK_CASES = {      # engineered segmentation score maps for the mask / bounding-box stage (120 x 160)
+    'one_blob': [(30, 70, 40, 90, 1.0)],
+    # the 21x21 dilation of single_obj_scoremap bridges 10 background pixels but not 11
+    'two_blobs_gap10': [(30, 60, 20, 50, 1.2), (30, 60, 60, 90, 1.0)],
+    'two_blobs_gap11': [(30, 60, 20, 50, 1.2), (30, 60, 61, 90, 1.0)],
+    'empty': [], 'full': [(0, 120, 0, 160, 1.0)], 'border': [(0, 12, 150, 160, 1.0)],
+}
+
+
+def blob_scoremap(case, H=120, W=160, strength=4.0, seed=0):
+    """[1,H,W,2] hand score map: background logit 1, rectangles (y0,y1,x0,x1,s) with fg logit s*strength, tiny noise."""
+    rng = np.random.default_rng(seed)
+    sm = np.zeros((1, H, W, 2), np.float32)
+    sm[..., 0] = 1.0
+    for (y0, y1, x0, x1, s) in MASK_CASES[case]:
+        sm[0, y0:y1, x0:x1, 1] = s * strength
+    sm += (rng.standard_normal(sm.shape) * 0.01).astype(np.float32)
+    return sm
+
+
+def lifting_scoremaps(seed, B, size=256):
+    """Seeded [B,size,size,21] score maps for the PosePriorNetwork entry point."""
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((B, size, size, 21)) * 0.3).astype(np.float32)

@@ -60,8 +60,6 @@ def test_product_never_imports_oracle_or_frameworks():
             m = bad.search(src)
             if m and not (f == 'dist.py' and 'torch' in m.group(0)):    # dist.py: torch.distributed plumbing only
                 raise AssertionError("%s: %s" % (os.path.join(dp, f), m.group(0)))
-            assert 'oracle' not in src.replace('oracle/', '').replace('the oracle', '').replace('oracle.', '').lower() \
-                or f in ('build.py',) or True
     code = "import sys; sys.path.insert(0, %r); import hand3d_amd, hand3d_amd.nets, hand3d_amd.utils.general; " \
            "assert 'oracle' not in sys.modules and 'torch' not in sys.modules and 'tensorflow' not in sys.modules" % ROOT
     subprocess.check_call([sys.executable, '-c', code])

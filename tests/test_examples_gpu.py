@@ -1,25 +1,117 @@
-"""The example harnesses (mirrors of run.py / eval*.py) run end to end on the GPU with synthetic data."""
+"""The example harnesses (mirrors of run.py / eval*.py) run end to end on the GPU with synthetic data, and the metric they
+print equals the metric of the same evaluation loop run with the ORACLE's networks on the same records (EvalUtil
+semantics, utils/general.py:522-611; loops: eval_full.py:69-92, eval2d.py:84-112, eval2d_gt_cropped.py:68-101,
+eval3d.py:79-105)."""
+import json
 import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
+
+from hand3d_amd import synth
+from oracle import general as G
+from oracle import nets as N
+from oracle import tf_ops as T
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'examples'))
+LIMIT = 2
 
 
-@pytest.mark.parametrize("cmd", [
-    ['run.py', '--synthetic'],
-    ['eval_full.py', '--synthetic', '--limit', '3'],
-    ['eval2d.py', '--synthetic', '--limit', '3'],
-    ['eval2d.py', '--synthetic', '--limit', '3', '--gt-cropped'],
-    ['eval3d.py', '--synthetic', '--limit', '3', '--variant', 'proposed'],
-    ['eval3d.py', '--synthetic', '--limit', '3', '--variant', 'local'],
-    ['eval3d.py', '--synthetic', '--limit', '3', '--variant', 'bottleneck'],
-], ids=lambda c: '_'.join(c))
-def test_example_harness(cmd):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', cmd[0])] + cmd[1:], capture_output=True,
-                         text=True, timeout=600, cwd=ROOT)
+def _run(script, *args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', script), '--synthetic'] + list(args),
+                         capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert ('EPE' in out.stdout) or ('wrist_xyz' in out.stdout)
+    return out.stdout
+
+
+def _result(stdout):
+    assert 'EPE' in stdout
+    line = [l for l in stdout.splitlines() if l.startswith('RESULT ')]
+    assert len(line) == 1, stdout[-500:]
+    return json.loads(line[0][7:])
+
+
+def _close(res, util, lo, hi, what):
+    mean, median, auc, _, _ = util.get_measures(lo, hi, 20)
+    print("%s: harness mean %.6g median %.6g auc %.4f | oracle loop mean %.6g median %.6g auc %.4f"
+          % (what, res['mean'], res['median'], res['auc'], mean, median, auc))
+    assert abs(res['mean'] - mean) <= 1e-4 * max(abs(mean), 1e-6), what
+    assert abs(res['median'] - median) <= 1e-4 * max(abs(median), 1e-6), what
+    assert abs(res['auc'] - auc) <= 1e-3, what
+
+
+def test_run_harness(gpu_engine, synth_weights):
+    """run.py: the printed centre / scale / wrist keypoints equal the oracle's for the five synthetic frames."""
+    rows = [json.loads(l) for l in _run('run.py').splitlines() if l.startswith('{')]
+    assert len(rows) == 5
+    for i, r in enumerate(rows):
+        img = ((synth.make_image(i) + 0.5) * 255.0).astype('float') / 255.0 - 0.5
+        o = N.inference(synth_weights, img[None].astype(np.float32), np.array([[1.0, 0.0]], np.float32), True)
+        assert r['center'] == o[3].tolist() and r['scale'] == float(o[2][0, 0])
+        hw = G.trafo_coords(G.detect_keypoints(o[4][0]), o[3], o[2], 256)
+        assert np.allclose(r['wrist_hw'], hw[0]) and np.abs(np.array(r['wrist_xyz']) - o[5][0, 0]).max() < 1e-4
+
+
+def test_eval_full_harness(gpu_engine, synth_weights, tmp_path):
+    from common import synthetic_stb_db
+    from hand3d_amd.data import BinaryDbReaderSTB
+    res = _result(_run('eval_full.py', '--limit', str(LIMIT)))
+    db = synthetic_stb_db(str(tmp_path / 'stb_eval.bin'), LIMIT)
+    util = G.EvalUtil()
+    for data in BinaryDbReaderSTB(mode='evaluation', shuffle=False, use_wrist_coord=False, path_to_db=db).get():
+        u8 = np.rint((data['image'] + 0.5) * 255.0).astype(np.uint8)
+        coord3d = N.inference(synth_weights, G.preprocess_u8(u8, 240, 320), data['hand_side'], True)[5]     # eval_full.py:50-57
+        xyz = np.squeeze(data['keypoint_xyz21'])
+        util.feed(xyz - xyz[0, :], np.ones(21), np.squeeze(coord3d) * np.squeeze(data['keypoint_scale']))   # :81-86
+    _close(res, util, 0.0, 0.050, 'eval_full')
+
+
+def test_eval2d_harness(gpu_engine, synth_weights, tmp_path):
+    from common import synthetic_rhd_db
+    from hand3d_amd.data import BinaryDbReader
+    res = _result(_run('eval2d.py', '--limit', str(LIMIT)))
+    db = synthetic_rhd_db(str(tmp_path / 'rhd_evaluation.bin'), LIMIT)
+    util = G.EvalUtil()
+    for data in BinaryDbReader(mode='evaluation', shuffle=False, use_wrist_coord=True, scale_to_size=True, path_to_db=db,
+                               engine=gpu_engine).get():
+        sm, _, scale_crop, center = N.inference2d(synth_weights, data['image'])                              # eval2d.py:58
+        hw = G.trafo_coords(G.detect_keypoints(np.squeeze(sm)), center, scale_crop, 256)
+        uv = np.stack([hw[:, 1], hw[:, 0]], 1)                      # scale = (240/240, 320/320), scale2orig_res = 1 (:97-105)
+        util.feed(np.squeeze(data['keypoint_uv21']), np.squeeze(data['keypoint_vis21']), uv)
+    _close(res, util, 0.0, 30.0, 'eval2d')
+
+
+def test_eval2d_gt_cropped_harness(gpu_engine, synth_weights, tmp_path):
+    from common import synthetic_rhd_db
+    from hand3d_amd.data import BinaryDbReader
+    res = _result(_run('eval2d.py', '--limit', str(LIMIT), '--gt-cropped'))
+    db = synthetic_rhd_db(str(tmp_path / 'rhd_evaluation.bin'), LIMIT)
+    util = G.EvalUtil()
+    for data in BinaryDbReader(mode='evaluation', shuffle=False, hand_crop=True, use_wrist_coord=False, path_to_db=db,
+                               engine=gpu_engine).get():
+        sm = T.resize_bilinear_legacy(N.posenet2d(synth_weights, data['image_crop'])[-1], 256, 256)         # :45-50
+        hw = G.detect_keypoints(np.squeeze(sm))
+        cs = np.squeeze(data['crop_scale'])
+        util.feed(np.squeeze(data['keypoint_uv21']) / cs, np.squeeze(data['keypoint_vis21']),
+                  np.stack([hw[:, 1], hw[:, 0]], 1) / cs)                                                    # :79-82
+    _close(res, util, 0.0, 30.0, 'eval2d_gt_cropped')
+
+
+@pytest.mark.parametrize('variant', ['proposed', 'local', 'bottleneck'])
+def test_eval3d_harness(gpu_engine, tmp_path, variant):
+    from common import synthetic_rhd_db
+    from hand3d_amd.data import BinaryDbReader
+    res = _result(_run('eval3d.py', '--limit', str(LIMIT), '--variant', variant))
+    db = synthetic_rhd_db(str(tmp_path / 'rhd_evaluation.bin'), LIMIT)
+    w = synth.make_weights(bottleneck=(variant == 'bottleneck'))
+    util = G.EvalUtil()
+    for data in BinaryDbReader(mode='evaluation', shuffle=False, hand_crop=True, use_wrist_coord=False, path_to_db=db,
+                               engine=gpu_engine).get():
+        rel, _, _ = N.poseprior_network(w, variant, data['scoremap'], data['hand_side'])                    # eval3d.py:60
+        xyz = np.squeeze(data['keypoint_xyz21'])
+        util.feed(xyz - xyz[0, :], np.ones(21), np.squeeze(rel) * np.squeeze(data['keypoint_scale']))       # :89-95
+    _close(res, util, 0.0, 0.050, 'eval3d ' + variant)

@@ -74,3 +74,61 @@ def test_e2e_golden_oracle_glue(synth_weights):
     assert np.array_equal(crop[:, ::16, ::16, :], g['image_crop_sub'])
     rel, _, _ = N.pose3d(synth_weights, g['conv7_7'], np.array([[1.0, 0.0]], np.float32))
     assert np.abs(rel - g['keypoint_coord3d']).max() < 1e-5
+
+
+# ---- fixtures written by executing the reference's own code (scripts/make_ref_fixtures.py) -----------------------------
+def test_oracle_matches_reference_code_fixtures(synth_weights):
+    """oracle == tests/golden/ref_*.npz.  Runs everywhere (the fixtures travel; /root/reference does not)."""
+    g = np.load(os.path.join(GOLD, 'ref_c1_inference.npz'))
+    for s in (0, 3):
+        k = 's%d_' % s
+        img = synth.make_batch(s, 1, 240, 320)
+        taps = {}
+        o = N.inference(synth_weights, img, g[k + 'hand_side'], True, taps=taps)
+        assert np.array_equal(np.packbits(taps['hand_mask'][0, :, :, 0].astype(np.uint8)), g[k + 'mask_packed'])
+        assert np.array_equal(o[3], g[k + 'center']) and np.array_equal(o[2], g[k + 'scale_crop'])
+        assert np.array_equal(o[4][0, ::8, ::8, :], g[k + 'scoremap32'])
+        assert np.abs(o[5] - g[k + 'keypoint_coord3d']).max() < 1e-6
+        assert np.array_equal(G.detect_keypoints(o[4][0]), g[k + 'kp_crop'])
+    m = np.load(os.path.join(GOLD, 'ref_mask_cases.npz'))
+    for rid in ('inf', 'fltmax'):
+        G.EMPTY_REDUCE = rid
+        try:
+            for case in synth.MASK_CASES:
+                mask = G.single_obj_scoremap(synth.blob_scoremap(case))
+                center, _, size = G.calc_center_bb(mask)
+                key = '%s_%s_' % (case, rid)
+                assert np.array_equal(np.packbits(mask[0, :, :, 0].astype(np.uint8)), m[key + 'mask_packed'])
+                assert np.array_equal(center, m[key + 'center']) and np.array_equal(size, m[key + 'size'])
+        finally:
+            G.EMPTY_REDUCE = 'inf'
+    p = np.load(os.path.join(GOLD, 'ref_poseprior_variants.npz'))
+    sm, hs = synth.lifting_scoremaps(5, 2), synth.hand_sides(2)
+    for v in ('direct', 'local', 'proposed'):
+        rel, c3d, R = N.poseprior_network(synth_weights, v, sm, hs)
+        assert np.abs(rel - p[v + '_rel']).max() < 2e-6 and np.abs(c3d - p[v + '_coord3d']).max() < 1e-6
+
+
+def test_kernels_on_interpreter_match_reference_code_fixtures(emu_engine, synth_weights):
+    """The product's kernels (CPU interpreter build) and host helpers vs the reference-code fixtures."""
+    from hand3d_amd.utils import general as PG
+    m = np.load(os.path.join(GOLD, 'ref_mask_cases.npz'))
+    for case in synth.MASK_CASES:
+        mask, center, size, _, _ = emu_engine.mask_from_scoremap(synth.blob_scoremap(case))
+        key = '%s_inf_' % case
+        assert np.array_equal(np.packbits(mask[0].astype(np.uint8)), m[key + 'mask_packed']), case
+        assert np.array_equal(center, m[key + 'center']) and np.array_equal(size, m[key + 'size']), case
+    p = np.load(os.path.join(GOLD, 'ref_poseprior_variants.npz'))
+    sm, hs = synth.lifting_scoremaps(5, 2), synth.hand_sides(2)
+    emu_engine.load_weight_dict({k: v for k, v in synth_weights.items() if k.startswith(('PosePrior', 'ViewpointNet'))})
+    emu_engine.finalize_weights()
+    for v in ('local', 'proposed'):
+        rel, c3d, R = emu_engine.poseprior(v, sm, hs)
+        assert np.abs(rel - p[v + '_rel']).max() < 1e-4 and np.abs(c3d - p[v + '_coord3d']).max() < 1e-4
+    e = np.load(os.path.join(GOLD, 'ref_evalutil.npz'))
+    u = PG.EvalUtil()
+    for gt, vis, pr in zip(e['gt'], e['vis'], e['pred']):
+        u.feed(gt, vis, pr)
+    mean, median, auc, pck, thr = u.get_measures(0.0, 30.0, 20)
+    assert np.isclose(mean, e['mean'], rtol=1e-13) and np.isclose(median, e['median'], rtol=1e-13)
+    assert np.isclose(auc, e['auc'], rtol=1e-13) and np.allclose(pck, e['pck'], rtol=1e-13) and np.array_equal(thr, e['thresholds'])

@@ -2,7 +2,8 @@
 
 Tolerances (BASELINE.json north_star): heat-maps 1e-3, 3-D keypoints 1e-4, max-abs, against the
 float64-accumulating oracle; integer/index outputs (masks, seeds, arg-max) bit-exact.
-PARITY UNPINNED against TF 1.3 itself (see oracle/__init__.py).
+The oracle itself is pinned to the reference's executed code (tests/test_reference_pin.py, tests/golden/ref_*.npz);
+TF 1.3's own kernels remain restated (oracle/__init__.py).
 """
 import numpy as np
 import pytest
@@ -367,26 +368,31 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
 
 
 def test_full_pipeline_batch32_winograd_active(net, synth_weights):
-    """The bench workload shape (B=32, 320x320): at this size the 3x3 layers with Cout % 128 == 0 run as
-    Winograd F(2x2,3x3).  Two of the 32 images are checked against the float64-accumulating oracle, and the
-    whole batch against the direct-kernel engine."""
+    """The bench workload shape (B=32, 320x320): at this size the 3x3 layers with Cout % 64 == 0 and the 7x7 layers run as
+    Winograd F(2x2,3x3).  EVERY image of the batch is checked against the oracle (two of them against its
+    float64-accumulating form, the rest against the float32 one), then the whole batch against the direct-kernel engine."""
+    from hand3d_amd.utils.general import EvalUtil
     img = synth.make_batch(3000, 32, 320, 320)
     hs = synth.hand_sides(32)
     o = net.engine.infer_full(img, hs, want_mask=True)
-    kernels = set(k for _, k, _, _, _ in net.engine.profile())
     net.engine.set_profiling(1)
     net.engine.infer_full(img, hs)
     kernels = set(k for _, k, _, _, _ in net.engine.profile())
     net.engine.set_profiling(0)
     assert any(k.startswith('conv_wino') for k in kernels), kernels
-    for i in (0, 17):
+    ev = EvalUtil()
+    worst = dict(scoremap=0.0, kpmap=0.0, coord3d=0.0)
+    for i in range(32):
         taps = {}
-        ref = N.inference(synth_weights, img[i:i + 1], hs[i:i + 1], True, acc=np.float64, taps=taps)
-        assert np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0])
-        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2])
-        assert np.abs(o['scoremap'][i:i + 1] - ref[0]).max() < TOL_HEATMAP
-        assert np.abs(o['kpmap'][i:i + 1] - ref[4]).max() < TOL_HEATMAP
-        assert np.abs(o['coord3d'][i:i + 1] - ref[5]).max() < TOL_KP3D
+        ref = N.inference(synth_weights, img[i:i + 1], hs[i:i + 1], True, acc=np.float64 if i in (0, 17) else np.float32, taps=taps)
+        assert np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0]), "image %d: hand mask differs" % i
+        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2]), i
+        worst['scoremap'] = max(worst['scoremap'], float(np.abs(o['scoremap'][i:i + 1] - ref[0]).max()))
+        worst['kpmap'] = max(worst['kpmap'], float(np.abs(o['kpmap'][i:i + 1] - ref[4]).max()))
+        worst['coord3d'] = max(worst['coord3d'], float(np.abs(o['coord3d'][i:i + 1] - ref[5]).max()))
+        ev.feed(ref[5][0], np.ones(21), o['coord3d'][i])
+    print("B=32 320x320, all 32 images vs oracle: worst %s, mean EPE %.3e" % (worst, ev.get_measures(0.0, 0.05, 20)[0]))
+    assert worst['scoremap'] < TOL_HEATMAP and worst['kpmap'] < TOL_HEATMAP and worst['coord3d'] < TOL_KP3D
     net.engine.set_option('conv_impl', 'direct')
     try:
         od = net.engine.infer_full(img, hs)

@@ -1,17 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- images/sec through the full ColorHandPose3D pipeline on N MI355X of one node.
 
-A "step" = one pass of ColorHandPose3DNetwork.inference() (HandSegNet -> mask/bbox/crop ->
-PoseNet2D -> PosePrior/Viewpoint -> heat-map upsample) over one synthetic batch per GPU that is
-already resident in HBM.  Weak scaling: every rank runs the same per-GPU batch (BASELINE config 4:
-256 images over 8 GPUs = 32 per GPU); the only collectives are the one-off RCCL weight broadcast
-(untimed setup) and the per-step gather of the [B,21,3] keypoints (timed).
+A "step" = one pass of ColorHandPose3DNetwork.inference() (HandSegNet -> mask/bbox/crop -> PoseNet2D ->
+PosePrior/Viewpoint -> heat-map upsample -> 2-D keypoints) over one synthetic batch per GPU that is already resident
+in HBM.  Weak scaling: every rank runs the same per-GPU batch (BASELINE config 4: 256 images over 8 GPUs = 32 per GPU);
+the only collectives are the one-off RCCL weight broadcast (untimed setup) and the per-step all-gather of the
+[B,21,3] keypoints (timed).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-torch is used for device memory and torch.distributed only (plumbing); all compute is libhp3d.so.
+No PyTorch in the measured path: device memory, copies, RCCL and the rendezvous go through libhp3d.so's C ABI and
+hand3d_amd/dist.py (the launcher above only starts the processes and exports RANK / WORLD_SIZE / MASTER_*).  torch is
+imported in exactly one place, the `cpu_baseline` leg, where torch-CPU (oneDNN) convolutions ARE the baseline.
+
+Protocol: W untimed warm-up steps; barrier + device sync; EXACTLY K steps timed with per-launch profiling OFF; device sync
++ barrier; max over ranks -> `value`.  Then a SEPARATE pass of K steps with HIP events around every launch (on the engine
+stream) gives the per-kernel durations behind `roofline` (reported with its own ms/step so the two can be compared).
 """
 import argparse
 import json
@@ -38,41 +44,87 @@ def parse():
     ap.add_argument('--height', type=int, default=320)
     ap.add_argument('--width', type=int, default=320)
     ap.add_argument('--workload', default='full', choices=['full', 'posenet'])
-    ap.add_argument('--cpu-images', type=int, default=5, help='oracle images timed for cpu_baseline (0 = skip)')
+    ap.add_argument('--cpu-seconds', type=float, default=20.0,
+                    help='budget of the cpu_baseline / epe_vs_oracle leg on rank 0 at N=1 (0 = skip)')
     ap.add_argument('--layers', action='store_true', help='print the per-layer table to stderr')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'f16'],
                     help="f32 = exact f32 MFMA (headline); f16 = half-precision trunks, BASELINE config 5 (looser parity)")
-    ap.add_argument('--comm', default='torch', choices=['torch', 'native'],
-                    help="weight broadcast: torch.distributed (RCCL) or the engine's own hp3d_comm_init + hp3d_bcast_weights")
-    ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (hp3d_set_option graph=1; small batches)')
-    ap.add_argument('--streams', type=int, default=1, help='engine contexts (HIP streams) per GPU; the per-GPU batch is split across them')
+    ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (hp3d_set_option graph=1)')
+    ap.add_argument('--option', action='append', default=[], metavar='KEY=VALUE', help='hp3d_set_option before the run (repeatable)')
+    ap.add_argument('--no-host-path', action='store_true', help='skip the PCIe-inclusive host_path measurement')
     return ap.parse_args()
 
 
-def cpu_baseline(weights, H, W, n_images, workload):
-    """The oracle (NumPy port of the reference's TF1.3 graph; OpenBLAS threads) on the host cores."""
-    from oracle import nets as onets
-    from hand3d_amd import synth
-    imgs = synth.make_batch(9000, n_images, H if workload == 'full' else 256, W if workload == 'full' else 256)
-    hs = synth.hand_sides(n_images)
-    t0 = time.time()
-    for i in range(n_images):
-        if workload == 'full':
-            onets.inference(weights, imgs[i:i + 1], hs[i:i + 1], True)
-        else:
-            onets.posenet2d(weights, imgs[i:i + 1])
-    dt = time.time() - t0
-    threads = os.cpu_count()
-    try:        # the GEMMs inside the oracle run on NumPy's BLAS pool: report the threads it really uses
-        from threadpoolctl import threadpool_info
-        blas = [p['num_threads'] for p in threadpool_info() if p.get('user_api') == 'blas']
-        if blas:
-            threads = max(blas)
-    except Exception:
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
         pass
-    return {"value": round(n_images / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "%d image(s) of the same workload through the NumPy oracle (float32, BLAS pool of %d threads on a "
-                      "%d-core host), %.1f s" % (n_images, threads, os.cpu_count(), dt)}
+    return 'unknown'
+
+
+def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s):
+    """rank 0, N = 1 only: the oracle (CPU restatement of the reference; SURVEY.md 8d recipe: NumPy glue + torch-CPU /
+    oneDNN convolutions on all cores) over the FIRST images of the very batch the GPU just processed -- one pass gives the
+    reported CPU baseline (bounded sample) and the parity of the GPU outputs against it (mean EPE, EvalUtil semantics)."""
+    import torch                                   # the baseline itself is torch-CPU; nothing else in this file uses it
+    from oracle import general as OG
+    from oracle import nets as onets
+    from oracle import tf_ops as OT
+    torch.set_num_threads(os.cpu_count() or 1)
+    OT.CONV_BACKEND = 'torch'
+    util = OG.EvalUtil()
+    worst_kp3d = worst_map = 0.0
+    n, t_used = 0, 0.0
+    try:
+        OT.conv2d_same(imgs[:1, :32, :32], weights['HandSegNet/conv1_1/weights'])                # thread-pool / oneDNN warm-up
+        while n < imgs.shape[0] and (n == 0 or t_used + t_used / n <= budget_s):
+            t0 = time.time()
+            if workload == 'full':
+                o = onets.inference(weights, imgs[n:n + 1], hs[n:n + 1], True)
+            else:
+                o = onets.posenet2d(weights, imgs[n:n + 1])
+            t_used += time.time() - t0
+            if workload == 'full':
+                util.feed(o[5][0], np.ones(21), gpu_out['coord3d'][n])
+                worst_kp3d = max(worst_kp3d, float(np.abs(o[5][0] - gpu_out['coord3d'][n]).max()))
+                worst_map = max(worst_map, float(np.abs(o[4][0, ::8, ::8] - gpu_out['sm32'][n]).max()))
+            else:
+                worst_map = max(worst_map, float(np.abs(o[2][0] - gpu_out['sm32'][n]).max()))
+            n += 1
+    finally:
+        OT.CONV_BACKEND = 'numpy'
+    cores = torch.get_num_threads()
+    cpu = {"value": round(n / t_used, 4), "unit": "images/s", "cores": cores, "kind": "port",
+           "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+           "sample": "%d image(s) of the same batch through the oracle (NumPy glue + torch-CPU/oneDNN float32 convolutions, "
+                     "torch.set_num_threads(%d)), %.1f s -- a CPU restatement baseline, not TensorFlow 1.3" % (n, cores, t_used)}
+    par = {"images": n, "max_abs_err_heatmap32": worst_map, "tolerance_heatmap": 1e-3}
+    if workload == 'full':
+        par.update({"mean_epe": float(util.get_measures(0.0, 0.05, 20)[0]), "max_abs_err_kp3d": worst_kp3d,
+                    "tolerance_kp3d": 1e-4,
+                    "what": "mean end-point error (EvalUtil, utils/general.py:522-611) of the GPU keypoint_coord3d against the "
+                            "oracle's on the same images, normalised units"})
+    return cpu, par
+
+
+def traffic_record(dom, workload_str):
+    """HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of THIS command (counters cannot be read
+    in-process): scripts/gpu_round.sh <tag> pmc -> scripts/summarize_prof.py -> profiles/<family>_traffic.json.  The number
+    is quoted only for the workload string it was measured on, together with the stamp the summariser wrote into the file
+    (profile tag, date, commit of the tree that was profiled)."""
+    tpath = os.path.join(ROOT, 'profiles', '%s_traffic.json' % dom)
+    try:
+        t = json.load(open(tpath))
+        if t.get('workload') != workload_str:
+            return None, None
+        return round(t['hbm_bytes_per_launch']), {"file": os.path.relpath(tpath, ROOT), "stamp": t.get('stamp', t.get('source')),
+                                                  "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate "
+                                                            "passes of this command, per launch"}
+    except Exception:
+        return None, None
 
 
 def main():
@@ -85,95 +137,74 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    import torch
-    import torch.distributed as dist
-    use_dist = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ   # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local)
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=torch.device('cuda', local))
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     from hand3d_amd import Engine, synth, arch
-    from hand3d_amd.dist import ShardedPipeline, gather_keypoints
-    eng = Engine(local)     # raises if libhp3d.so is missing: no fallback
+    from hand3d_amd.dist import Rendezvous, ShardedPipeline
+    eng = Engine(local)     # raises if libhp3d.so is missing or no GPU is visible: no fallback
+    rdzv = Rendezvous.from_env() if launched else Rendezvous(0, 1)
+    sp = ShardedPipeline(eng, rank, world, rdzv)
     B, H, W = a.batch, a.height, a.width
     weights = synth.make_weights() if rank == 0 else None
-    if a.comm == 'native':
-        ShardedPipeline(eng, rank, world).sync_weights_native(weights, dtype=a.dtype)
-    else:
-        ShardedPipeline(eng, rank, world).sync_weights(weights, device=dev, dtype=a.dtype)
-    # extra contexts on the same GPU: independent HIP streams whose kernels overlap (one context's tail /
-    # prologue / launch gaps are filled by the other's bulk); they get the weights by a device-to-device blob copy
-    engines = [eng]
-    for _ in range(a.streams - 1):
-        e2 = Engine(local)
-        blob = torch.empty((eng.blob_bytes() + 3) // 4, dtype=torch.float32, device=dev)
-        eng.blob_export(blob.data_ptr())
-        e2.blob_import(blob.data_ptr(), eng.nets_mask())
-        del blob
-        engines.append(e2)
+    # native RCCL (hp3d_comm_init + hp3d_bcast_weights) whenever a launcher started us -- also at world size 1, so that a
+    # single-GPU box still exercises the exchange
+    sp.sync_weights(weights, dtype=a.dtype, use_comm=launched)
     if a.graph:
-        for e in engines:
-            e.set_option('graph', '1')
-    assert B % len(engines) == 0, "--batch must be divisible by --streams"
-    Bs = B // len(engines)
+        eng.set_option('graph', '1')
+    for kv in a.option:
+        eng.set_option(*kv.split('=', 1))
 
     # synthetic inputs, resident in HBM before the timed region
     Hi, Wi = (H, W) if a.workload == 'full' else (256, 256)
-    img = torch.from_numpy(synth.make_batch(1000 + rank * B, B, Hi, Wi)).to(dev)
-    hs = torch.from_numpy(synth.hand_sides(B)).to(dev)
-    coord = torch.zeros(B, 21, 3, device=dev)
-    kpmap = torch.empty(B, 256, 256, 21, device=dev)
-    sm = [torch.empty(B, 32, 32, 21, device=dev) for _ in range(3)]
-    torch.cuda.synchronize(dev)
+    img_np = synth.make_batch(1000 + rank * B, B, Hi, Wi)
+    hs_np = synth.hand_sides(B)
+    d_img, d_hs = eng.to_device(img_np), eng.to_device(hs_np)
+    d_coord = eng.dev_alloc(B * 63 * 4)
+    d_kpmap = eng.dev_alloc(B * 256 * 256 * 21 * 4)
+    d_kphw = eng.dev_alloc(B * 42 * 8)
+    d_sm = [eng.dev_alloc(B * 32 * 32 * 21 * 4) for _ in range(3)]
+    eng.sync()
 
     def step():
         if a.workload == 'full':
-            for i, e in enumerate(engines):     # stream-ordered enqueue, no host sync in between
-                e.infer_full_dev(Bs, H, W, img[i * Bs:].data_ptr(), hs[i * Bs:].data_ptr(),
-                                 kpmap=kpmap[i * Bs:].data_ptr(), coord3d=coord[i * Bs:].data_ptr())
-            for e in engines:
-                e.sync()
-            return gather_keypoints(coord, n_total=B * world)
-        eng.lib.hp3d_posenet2d_dev(eng.h, B, 256, 256, img.data_ptr(), sm[0].data_ptr(), sm[1].data_ptr(), sm[2].data_ptr())
+            eng.infer_full_dev(B, H, W, int(d_img), int(d_hs), kpmap=int(d_kpmap), coord3d=int(d_coord), kp_hw=int(d_kphw))
+            eng.sync()
+            return sp.gather_keypoints(d_coord, B) if world > 1 else None
+        eng.lib.hp3d_posenet2d_dev(eng.h, B, 256, 256, int(d_img), int(d_sm[0]), int(d_sm[1]), int(d_sm[2]))
         eng.sync()
-        return sm[2]
+        return None
 
     for _ in range(a.warmup):
         step()
-    for e in engines:
-        e.set_profiling(2)
-    # HIP events on the engine stream around every launch, accumulated over the K steps
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
+    # ---- the timed region: profiling off (no per-launch events; hipGraph replay, if asked for, really replays) ----------
+    eng.set_profiling(0)
+    rdzv.barrier()
+    eng.sync()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        out = step()
-    torch.cuda.synchronize(dev)
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        step()
+    eng.sync()
+    rdzv.barrier()
+    dt = rdzv.max(time.perf_counter() - t0)
 
-    rows = []
-    for e in engines:
-        rows += e.profile()
-        e.set_profiling(0)
+    # ---- separate profiled pass: HIP events around every launch on the engine stream, accumulated over K steps ----------
+    eng.set_profiling(2)
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    eng.sync()
+    dt_prof = time.perf_counter() - t1
+    rows = eng.profile()
+    eng.set_profiling(0)
+
     if rank == 0:
-        # ---- roofline of the dominant kernel family ------------------------------------------------------
-        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 layers), conv_mfma (direct implicit GEMM), glue
+        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 / 7x7 layers), conv_mfma (direct implicit GEMM), glue
         fam = {}
         for name, kern, ms, fl, by in rows:
             k = 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else kern
-            # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter
-            # as nine 3x3 blocks 9*16 per 4*49
+            # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
+            # nine 3x3 blocks 9*16 per 4*49
             exe = (144.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k == 'conv_wino' else 1.0
             f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
             f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
@@ -182,11 +213,19 @@ def main():
 
         def roof_of(k):
             ms, fl, by, n, fle = fam[k]
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            # `achieved` stays ALGORITHMIC (direct-conv FLOPs); `mfma_executed` is what the matrix cores ran
-            exe = fle / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            return {"bound": "mfma", "kernel": k, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "mfma_executed": round(exe, 2), "mfma_executed_frac": round(exe / peak, 4),
+            sec = ms * 1e-3
+            if k == 'conv_first_3x3_c3':          # the one HBM-bound convolution (0.2 GFLOP per 13 MB of output per image)
+                ach = by / sec / 1e9 if sec > 0 else 0.0
+                return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                        "frac": round(ach / PEAK_HBM_GBPS, 4), "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
+                        "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2), "share_of_gpu_time": round(ms / total_ms, 4)}
+            alg = fl / sec / 1e12 if sec > 0 else 0.0
+            exe = fle / sec / 1e12 if sec > 0 else 0.0
+            # `achieved` / `frac` = what the matrix cores EXECUTE against their dense peak (<= 1 by construction);
+            # `achieved_algorithmic` = direct-form FLOPs / time, which Winograd lifts above the executed rate
+            return {"bound": "mfma", "kernel": k, "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(exe / peak, 4), "achieved_algorithmic": round(alg, 2),
+                    "algorithmic_over_executed": round(alg / exe, 3) if exe > 0 else None,
                     "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
                     "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
                     "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
@@ -194,19 +233,13 @@ def main():
         dom = max(fam, key=lambda k: fam[k][0])
         roof = roof_of(dom)
         if dom == 'conv_wino':
-            roof["note"] = ("achieved = direct-form (algorithmic) FLOPs / time; the kernel is float32 Winograd F(2x2,3x3), "
-                            "which executes 16/36 of them (7x7 layers as nine 3x3 blocks: 144/196), so frac can exceed 1; mfma_executed_frac is the matrix-core "
-                            "utilisation against the same dense f32 peak")
-        # HBM bytes per launch come from the PMC passes of the SAME command (scripts/gpu_round.sh ... pmc ->
-        # scripts/summarize_prof.py -> profiles/<family>_traffic.json); counters cannot be read in-process.
-        roof["traffic"] = None
-        roof["traffic_unit"] = "HBM bytes per launch (PMC, profiles/%s_traffic.json)" % dom
-        tpath = os.path.join(ROOT, 'profiles', '%s_traffic.json' % dom)
-        if a.workload == 'full' and a.dtype == 'f32' and (B, H, W) == (32, 320, 320) and os.path.exists(tpath):
-            try:
-                roof["traffic"] = round(json.load(open(tpath))['hbm_bytes_per_launch'])
-            except Exception:
-                pass
+            roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
+                            "blocks: 144/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
+        workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 %s in HBM, %d images/GPU/step" % (H, W, a.dtype, B)) \
+            if a.workload == 'full' else ("inference_pose2d, 256x256x3 %s in HBM, %d images/GPU/step" % (a.dtype, B))
+        roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str)
+        roof["timing"] = "HIP events on the engine stream around each launch, separate pass of %d steps (%.3f ms/step profiled)" % (
+            a.steps, dt_prof / a.steps * 1e3)
         others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0]) if k != dom and k.startswith('conv')]
         if a.layers:
             agg = {}
@@ -217,9 +250,43 @@ def main():
             for (name, kern), (ms_, fl_, by_, n_) in agg.items():
                 print("%-28s %-34s %9.3f %9.1f %9.0f" % (name, kern, ms_ / a.steps, fl_ / ms_ / 1e9 if ms_ else 0,
                                                          by_ / ms_ / 1e6 if ms_ else 0), file=sys.stderr)
-        cpu = None
-        if world == 1 and a.cpu_images > 0:
-            cpu = cpu_baseline(weights, H, W, a.cpu_images, a.workload)
+
+        # ---- PCIe-inclusive rate (never `value`): pinned host frames in -> 3-D + 2-D keypoints out on the host, the upload
+        #      of batch n+1 overlapped with the kernels of batch n (hp3d_upload_async on a second stream) ------------------
+        host_path = None
+        if world == 1 and a.workload == 'full' and not a.no_host_path:
+            pin = [eng.pinned_empty((B, H, W, 3)) for _ in range(2)]
+            dev = [d_img, eng.dev_alloc(B * H * W * 3 * 4)]
+            for p in pin:
+                p[...] = img_np
+            eng.upload_async(dev[0], pin[0]); eng.wait_upload()
+            outs = None
+            th = time.perf_counter()
+            for i in range(a.steps):
+                cur, nxt = i & 1, (i + 1) & 1
+                if i + 1 < a.steps:
+                    eng.upload_async(dev[nxt], pin[nxt])
+                eng.infer_full_dev(B, H, W, int(dev[cur]), int(d_hs), coord3d=int(d_coord), kp_hw=int(d_kphw))
+                outs = (eng.to_host(d_coord, (B, 21, 3)), eng.to_host(d_kphw, (B, 21, 2), np.float64))     # blocking D2H
+                eng.wait_upload()
+            dth = time.perf_counter() - th
+            host_path = {"value": round(B * a.steps / dth, 2), "unit": "images/s", "ms_per_step": round(dth / a.steps * 1e3, 3),
+                         "what": "pinned float32 frames on the host -> keypoint_coord3d [B,21,3] + 2-D keypoints [B,21,2] on the "
+                                 "host per step; H2D of step n+1 overlapped with the kernels of step n; heat-maps stay on the device"}
+            dev[1].free()
+
+        cpu = parity = None
+        if world == 1 and a.cpu_seconds > 0:
+            gpu_out = {'coord3d': eng.to_host(d_coord, (B, 21, 3)) if a.workload == 'full' else None}
+            if a.workload == 'full':
+                eng.infer_full_dev(B, H, W, int(d_img), int(d_hs), kpmap=int(d_kpmap), coord3d=int(d_coord))
+                eng.sync()
+                gpu_out['coord3d'] = eng.to_host(d_coord, (B, 21, 3))
+                nchk = min(B, 8)
+                gpu_out['sm32'] = eng.to_host(d_kpmap, (nchk, 256, 256, 21))[:, ::8, ::8]
+            else:
+                gpu_out['sm32'] = eng.to_host(d_sm[2], (B, 32, 32, 21))
+            cpu, parity = oracle_leg(weights, img_np[:8], hs_np[:8], gpu_out, a.workload, a.cpu_seconds)
         n_img = B * world * a.steps
         fl_img = arch.pipeline_flops(H, W)
         res = {
@@ -228,18 +295,19 @@ def main():
             "value": round(n_img / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded images, seeded fan-in-scaled weights)",
-            "config": {"workload": ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step"
-                                    % (H, W, B)) if a.workload == 'full' else
-                                   ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B),
+            "config": {"workload": workload_str,
                        "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
-                       "parallelism": "batch-shard x%d (no data-path collective; keypoint all_gather per step)%s" % (
-                           world, "" if len(engines) == 1 else "; %d HIP streams per GPU" % len(engines)),
+                       "parallelism": "batch-shard x%d, one process per GPU, no data-path collective; weights by hp3d_bcast_weights "
+                                      "and a per-step keypoint all-gather (RCCL through the C ABI, TCP rendezvous; no torch)" % world,
+                       "hipgraph": bool(a.graph), "options": a.option,
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
-            "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu, "epe_vs_oracle": parity,
+            "host_path": host_path,
         }
+        if a.graph:
+            res["config"]["hipgraph_replays"] = eng.counter('graph_replays')
         os.write(json_fd, (json.dumps(res) + '\n').encode())
-    if use_dist:
-        dist.destroy_process_group()
+    sp.close()
 
 
 if __name__ == '__main__':

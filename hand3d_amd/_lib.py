@@ -36,9 +36,14 @@ _SIGNATURES = {
     'hp3d_nets_mask': (C.c_int, [_ctx]),
     'hp3d_infer_full': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
     'hp3d_infer_full_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 9),
+    'hp3d_infer_full_kp': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11),
+    'hp3d_infer_full_kp_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 11),
+    'hp3d_infer_full_kp_u8': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 10),
     'hp3d_infer_full_u8': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8),
     'hp3d_preprocess_u8': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'hp3d_infer_2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
+    'hp3d_infer_2d_kp': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 7),
+    'hp3d_detect_keypoints': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     'hp3d_handsegnet': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 3),
     'hp3d_posenet2d': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
     'hp3d_posenet2d_dev': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 4),
@@ -54,6 +59,14 @@ _SIGNATURES = {
     'hp3d_mask_from_scoremap': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 5),
     'hp3d_fc': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     'hp3d_argmax2d': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    'hp3d_dev_alloc': (C.c_int, [_ctx, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'hp3d_dev_free': (C.c_int, [_ctx, C.c_void_p]),
+    'hp3d_host_alloc': (C.c_int, [_ctx, C.c_size_t, C.POINTER(C.c_void_p)]),
+    'hp3d_host_free': (C.c_int, [_ctx, C.c_void_p]),
+    'hp3d_memcpy': (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    'hp3d_upload_async': (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_size_t]),
+    'hp3d_wait_upload': (C.c_int, [_ctx]),
+    'hp3d_get_counter': (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_longlong)]),
     'hp3d_set_profiling': (C.c_int, [_ctx, C.c_int]),
     'hp3d_prof_count': (C.c_int, [_ctx]),
     'hp3d_prof_get': (C.c_int, [_ctx, C.c_int, C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_float),
@@ -63,6 +76,7 @@ _SIGNATURES = {
     'hp3d_comm_init': (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     'hp3d_bcast_weights': (C.c_int, [_ctx, C.c_int]),
     'hp3d_allgather': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
+    'hp3d_allgather_dev': (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p]),
     'hp3d_comm_destroy': (C.c_int, [_ctx]),
     'hp3d_crc32c': (C.c_uint32, [C.c_void_p, C.c_size_t]),
 }
@@ -111,6 +125,33 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class DevBuf(object):
+    """A device allocation owned through the C ABI (hp3d_dev_alloc / hp3d_dev_free); int(buf) is the device address."""
+
+    def __init__(self, engine, ptr, nbytes):
+        self.engine, self.ptr, self.nbytes = engine, ptr, nbytes
+
+    def __int__(self):
+        return self.ptr
+
+    def __index__(self):
+        return self.ptr
+
+    def at(self, offset_bytes):
+        return self.ptr + int(offset_bytes)
+
+    def free(self):
+        if self.ptr and self.engine is not None and self.engine.h:
+            self.engine.lib.hp3d_dev_free(self.engine.h, C.c_void_p(self.ptr))
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Engine(object):
     """One hp3d_ctx: a device, a stream, packed weights and a pre-allocated arena."""
 
@@ -122,9 +163,13 @@ class Engine(object):
             raise Hp3dError("hp3d_create(%d) failed: %s" % (device, self.lib.hp3d_last_error(None).decode()))
         self.h = h
         self.device = device
+        self._pinned = []
 
     def close(self):
         if getattr(self, 'h', None):
+            for p in getattr(self, '_pinned', []):
+                self.lib.hp3d_host_free(self.h, C.c_void_p(p))
+            self._pinned = []
             self.lib.hp3d_destroy(self.h)
             self.h = None
 
@@ -195,10 +240,14 @@ class Engine(object):
             'kpmap': np.empty((B, 256, 256, 21), np.float32) if 'kpmap' in outputs else None,
             'coord3d': np.empty((B, 21, 3), np.float32) if 'coord3d' in outputs else None,
             'mask': np.empty((B, H, W), np.float32) if want_mask else None,
+            # detect_keypoints / trafo_coords on the device (utils/general.py:331-357): int32 (row, col) in the crop and
+            # float64 (row, col) in the image; need no 'kpmap'
+            'kp_crop': np.empty((B, 21, 2), np.int32) if 'kp_crop' in outputs else None,
+            'kp_hw': np.empty((B, 21, 2), np.float64) if 'kp_hw' in outputs else None,
         }
-        self._chk(self.lib.hp3d_infer_full(self.h, B, H, W, _ptr(image), _ptr(hand_side), _ptr(o['scoremap']),
-                                           _ptr(o['crop']), _ptr(o['scale']), _ptr(o['center']), _ptr(o['kpmap']),
-                                           _ptr(o['coord3d']), _ptr(o['mask'])))
+        self._chk(self.lib.hp3d_infer_full_kp(self.h, B, H, W, _ptr(image), _ptr(hand_side), _ptr(o['scoremap']),
+                                              _ptr(o['crop']), _ptr(o['scale']), _ptr(o['center']), _ptr(o['kpmap']),
+                                              _ptr(o['coord3d']), _ptr(o['mask']), _ptr(o['kp_crop']), _ptr(o['kp_hw'])))
         return o
 
     def infer_full_u8(self, image_u8, hand_side, H=240, W=320, want_mask=False):
@@ -207,6 +256,7 @@ class Engine(object):
         hand_side = _f32(hand_side)
         assert img.ndim == 4 and img.shape[3] == 3, "image must be [B,Hin,Win,3] uint8"
         B, Hin, Win, _ = img.shape
+        assert hand_side.shape == (B, 2), "hand_side must be [B,2]"
         o = {'scoremap': np.empty((B, H, W, 2), np.float32), 'crop': np.empty((B, 256, 256, 3), np.float32),
              'scale': np.empty((B, 1), np.float32), 'center': np.empty((B, 2), np.float32),
              'kpmap': np.empty((B, 256, 256, 21), np.float32), 'coord3d': np.empty((B, 21, 3), np.float32),
@@ -224,11 +274,16 @@ class Engine(object):
         return out
 
     def infer_full_dev(self, B, H, W, image_ptr, hand_side_ptr, scoremap=0, crop=0, scale=0, center=0, kpmap=0,
-                       coord3d=0, mask=0):
-        """Device-pointer variant (ints); stream-ordered, call sync() before reading."""
-        v = lambda p: C.c_void_p(p) if p else None
-        self._chk(self.lib.hp3d_infer_full_dev(self.h, B, H, W, v(image_ptr), v(hand_side_ptr), v(scoremap), v(crop),
-                                               v(scale), v(center), v(kpmap), v(coord3d), v(mask)))
+                       coord3d=0, mask=0, kp_crop=0, kp_hw=0):
+        """Device-pointer variant (ints); stream-ordered, call sync() before reading.  kp_crop (int32 [B,21,2]) /
+        kp_hw (float64 [B,21,2]): detect_keypoints / trafo_coords evaluated on the device."""
+        v = lambda p: C.c_void_p(int(p)) if p else None
+        if kp_crop or kp_hw:
+            self._chk(self.lib.hp3d_infer_full_kp_dev(self.h, B, H, W, v(image_ptr), v(hand_side_ptr), v(scoremap), v(crop),
+                                                      v(scale), v(center), v(kpmap), v(coord3d), v(mask), v(kp_crop), v(kp_hw)))
+        else:
+            self._chk(self.lib.hp3d_infer_full_dev(self.h, B, H, W, v(image_ptr), v(hand_side_ptr), v(scoremap), v(crop),
+                                                   v(scale), v(center), v(kpmap), v(coord3d), v(mask)))
 
     def infer_2d(self, image):
         image = _f32(image)
@@ -240,6 +295,29 @@ class Engine(object):
         center = np.empty((B, 2), np.float32)
         self._chk(self.lib.hp3d_infer_2d(self.h, B, H, W, _ptr(image), _ptr(kp), _ptr(crop), _ptr(scale), _ptr(center)))
         return kp, crop, scale, center
+
+    def infer_2d_keypoints(self, image, want_scoremap=False):
+        """inference2d + detect_keypoints + trafo_coords on the device (eval2d.py:58,93-94): returns
+        (kp_crop int32 [B,21,2], kp_hw float64 [B,21,2], scale_crop, center[, keypoints_scoremap])."""
+        image = _f32(image)
+        assert image.ndim == 4 and image.shape[3] == 3, "image must be [B,H,W,3]"
+        B, H, W, _ = image.shape
+        kp = np.empty((B, 256, 256, 21), np.float32) if want_scoremap else None
+        scale = np.empty((B, 1), np.float32)
+        center = np.empty((B, 2), np.float32)
+        kpc = np.empty((B, 21, 2), np.int32)
+        kph = np.empty((B, 21, 2), np.float64)
+        self._chk(self.lib.hp3d_infer_2d_kp(self.h, B, H, W, _ptr(image), _ptr(kp), None, _ptr(scale), _ptr(center),
+                                            _ptr(kpc), _ptr(kph)))
+        return (kpc, kph, scale, center, kp) if want_scoremap else (kpc, kph, scale, center)
+
+    def detect_keypoints(self, scoremap, out_hw=(256, 256)):
+        """detect_keypoints(resize_images(scoremap, out_hw)) per image: [B,h,w,C] -> int32 [B,C,2]."""
+        x = _f32(scoremap)
+        B, h, w, Cc = x.shape
+        out = np.empty((B, Cc, 2), np.int32)
+        self._chk(self.lib.hp3d_detect_keypoints(self.h, _ptr(x), B, h, w, Cc, int(out_hw[0]), int(out_hw[1]), _ptr(out)))
+        return out
 
     def handsegnet(self, image, want_small=False):
         image = _f32(image)
@@ -353,6 +431,11 @@ class Engine(object):
     def set_profiling(self, on):
         self._chk(self.lib.hp3d_set_profiling(self.h, int(on)))
 
+    def counter(self, name):
+        v = C.c_longlong()
+        self._chk(self.lib.hp3d_get_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def get_timing(self):
         """{stage: GPU ms} over the profiled launches (hp3d_get_timing; stages: TIMING_STAGES)."""
         buf = (C.c_float * len(TIMING_STAGES))()
@@ -380,8 +463,47 @@ class Engine(object):
         self._chk(self.lib.hp3d_allgather(self.h, _ptr(a), a.size, _ptr(out)))
         return out
 
+    def allgather_dev(self, dev_buf, count, world):
+        """all-gather straight from a device buffer of `count` floats per rank -> float32 [world * count] on the host."""
+        out = np.empty(int(world) * int(count), np.float32)
+        self._chk(self.lib.hp3d_allgather_dev(self.h, C.c_void_p(int(dev_buf)), int(count), _ptr(out)))
+        return out
+
     def comm_destroy(self):
         self._chk(self.lib.hp3d_comm_destroy(self.h))
+
+    # -- device / pinned host memory through the C ABI (no torch) ---------------------------------------
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._chk(self.lib.hp3d_dev_alloc(self.h, int(nbytes), C.byref(p)))
+        return DevBuf(self, p.value, int(nbytes))
+
+    def to_device(self, array):
+        """Copy a NumPy array into a fresh device buffer (blocking)."""
+        a = np.ascontiguousarray(array)
+        buf = self.dev_alloc(a.nbytes)
+        self._chk(self.lib.hp3d_memcpy(self.h, C.c_void_p(buf.ptr), _ptr(a), a.nbytes, 0))
+        return buf
+
+    def to_host(self, buf, shape, dtype=np.float32, offset_bytes=0):
+        out = np.empty(shape, dtype)
+        self._chk(self.lib.hp3d_memcpy(self.h, _ptr(out), C.c_void_p(int(buf) + int(offset_bytes)), out.nbytes, 1))
+        return out
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """NumPy array over page-locked host memory (for hp3d_upload_async); keep the returned array alive."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._chk(self.lib.hp3d_host_alloc(self.h, n, C.byref(p)))
+        arr = np.frombuffer((C.c_char * n).from_address(p.value), dtype=dtype).reshape(shape)
+        self._pinned.append(p.value)
+        return arr
+
+    def upload_async(self, buf, pinned_array):
+        self._chk(self.lib.hp3d_upload_async(self.h, C.c_void_p(int(buf)), _ptr(pinned_array), pinned_array.nbytes))
+
+    def wait_upload(self):
+        self._chk(self.lib.hp3d_wait_upload(self.h))
 
     def profile(self):
         """[(layer, kernel, ms, flops, bytes)] of the last whole-path call."""

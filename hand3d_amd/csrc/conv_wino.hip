@@ -30,6 +30,7 @@
 //     the SAME 16 planes (the output transform is linear) -- a 3x3 layer with 9 x Cin virtual channels: 144 instead
 //     of 196 multiplies per 2x2 outputs, 45 steps per item.
 #include "hp3d_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 
@@ -52,9 +53,13 @@ template <int NT> struct WinoCfg {
     static constexpr int PL_PER_BASE = NT == 32 ? 14 : 16;   // planes reachable from one ds_read base (16-bit immediate)
 };
 
-template <bool POOL, int NT, int NSUB>
+// SPLITK (small batches: too few items to fill the chip): a work item additionally owns a contiguous range of the channel
+// steps; it stores RAW partial outputs (the output transform is linear, so partial sums of M transform to partial sums of
+// Y) into p.out = [ksplit][B*Ho*Wo][Cout], and conv_splitk_reduce adds them in split order (+ bias, activation).
+template <bool POOL, int NT, int NSUB, bool SPLITK>
 HP3D_KERNEL2(256, 1)
 void conv_wino_kernel(const ConvParams p) {
+    static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
     using Cfg = WinoCfg<NT>;
     constexpr int WCK = Cfg::CK, WLDA = Cfg::LDA, WTILES = NT, PLANE_FLOATS = Cfg::PLANE_FLOATS, VBUF_FLOATS = Cfg::VBUF_FLOATS;
     constexpr int NQ = Cfg::NQ, G = Cfg::G, COUTS = Cfg::COUTS;
@@ -75,7 +80,8 @@ void conv_wino_kernel(const ConvParams p) {
     const int TXn = p.tiles_x, TYn = p.tiles_y, per_img = TXn * TYn;
     const int tile_blocks = (p.B * per_img + WTILES - 1) / WTILES;
     const int ncy = p.Cout / COUTS;
-    const int nitems = tile_blocks * ncy;
+    const int per_split = tile_blocks * ncy;                  // items of one channel split
+    const int nitems = per_split * (SPLITK ? p.ksplit : 1);
     auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) {
         tb = id / per_img;
         const int r = id - tb * per_img;
@@ -85,7 +91,7 @@ void conv_wino_kernel(const ConvParams p) {
         tyy = band * 4 + rem - txx * rows;
     };
     const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
-    auto table_write = [&](int tblock, int parity) {
+    auto table_write = [&](int tblock, int parity, int kz) {
         if (tid < WTILES) {
             int tb, tyy, txx;
             tile_decode(tblock * WTILES + tid, tb, tyy, txx);
@@ -94,7 +100,7 @@ void conv_wino_kernel(const ConvParams p) {
                 if (POOL) {
                     if (tyy < Hs && txx < Ws) off = ((tb * Hs + tyy) * Ws + txx) * p.out_cs;
                 } else {
-                    off = ((tb * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
+                    off = (((SPLITK ? kz * p.B + tb : tb) * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
                     fl = (2 * txx + 1 < Ws ? 1 : 0) | (2 * tyy + 1 < Hs ? 2 : 0);
                 }
             }
@@ -125,15 +131,15 @@ void conv_wino_kernel(const ConvParams p) {
                 wv[r * 4 + c] = in ? wbase + (r * p.W + c) * cs4 : OOR;
             }
     };
-    auto loader_setup = [&](int tblock, bool valid) {
+    auto loader_setup = [&](int tblock, bool valid, int sub) {
         int lb, lty, ltx;
         tile_decode(tblock * WTILES + lt, lb, lty, ltx);
         if (NSUB > 1) { cb = valid ? lb : p.B; cty = lty; ctx_ = ltx; }
-        window_offsets(valid, lb, lty, ltx, 0);
+        window_offsets(valid, lb, lty, ltx, (NSUB > 1 && SPLITK) ? sub : 0);
     };
     auto loader_shift = [&](int sub) { window_offsets(true, cb, cty, ctx_, sub); };
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
-    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
+    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
 
     f32x4 d[16];
     auto window_fetch = [&](int soff) {
@@ -208,37 +214,47 @@ void conv_wino_kernel(const ConvParams p) {
     };
 
     // ---- first item: the only exposed prologue -------------------------------------------------------------
+    // item -> (channel split kz, cout block cy, tile block); split kz owns the steps [s0, s1) (>= 2 each)
+    auto split_of = [&](int it, int& kz, int& cy_, int& tb_) {
+        kz = SPLITK ? it / per_split : 0;
+        const int r = SPLITK ? it - kz * per_split : it;
+        cy_ = r / tile_blocks;
+        tb_ = r - cy_ * tile_blocks;
+    };
+    auto first_step_of = [&](int kz) { return SPLITK ? (kz * nsteps) / p.ksplit : 0; };
     int item = blockIdx.x;
-    int cy = item / tile_blocks, tblock = item - cy * tile_blocks;
-    loader_setup(tblock, true);
-    table_write(tblock, 0);
+    int kz, cy, tblock;
+    split_of(item, kz, cy, tblock);
+    int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
+    loader_setup(tblock, true, s0 / csteps);
+    table_write(tblock, 0, kz);
     int wvoff = (cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
-    window_fetch(0);
-    b_fetch(0, wvoff, soff_of(0, 0));
-    b_fetch(1, wvoff, soff_of(1, 0));
-    b_fetch(2, wvoff, soff_of(2, 0));
+    window_fetch((s0 % csteps) * (WCK * 4));
+    b_fetch(0, wvoff, soff_of(0, s0));
+    b_fetch(1, wvoff, soff_of(1, s0));
+    b_fetch(2, wvoff, soff_of(2, s0));
     transform_commit(0);
     __syncthreads();
     int cur = 0;
 
     for (int k = 0;; ++k) {
-        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff;
+        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0;
         const int n_item = item + (int)gridDim.x;      // static round robin (a global work counter measured 0.5 % slower:
                                                        // its returning atomic sits in the in-order vmcnt queue of wave 0)
         const int co = cy * COUTS + wcout * 32 + li;
-        const float bias = p.bias[co];           // in flight during the item, used in the epilogue
+        const float bias = SPLITK ? 0.f : p.bias[co];           // in flight during the item, used in the epilogue
 
         // one step (32 or 16 channels): 16 planes x 16 or 8 MFMAs on V[cur]; the first step of an item starts the accumulators
         // from the inline constant 0
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
-            const bool lasts = step + 1 == nsteps;
+            const bool lasts = step + 1 == s1;
             // Loads return in issue order (one vmcnt counter), so the first wait on a weight fragment issued AFTER
             // the window loads also waits for the windows: the ring is topped up to 4 planes (0..3) first, the
             // windows go next, and B(p+4) is issued behind plane p's MFMAs -- the windows (the next step's, or the
             // next item's first) then have 4 planes (~1.8 us) to arrive before anything depends on them.
             const int nvoff = lasts ? n_wvoff : wvoff;
-            const int nstep = lasts ? 0 : step + 1;
+            const int nstep = lasts ? n_s0 : step + 1;
             ab0 = cur * (VBUF_FLOATS * 4) + va_lane0;
             ab1 = NT == 32 ? ab0 + 14 * PLANE_FLOATS * 4 : cur * (VBUF_FLOATS * 4) + va_lane1;
             HP3D_OPAQUE_V(ab0);
@@ -246,9 +262,9 @@ void conv_wino_kernel(const ConvParams p) {
             a_fetch(0, 0);                       // first: plane 0's MFMAs wait for exactly this
             b_fetch(3, wvoff, soff_of(3, step));
             // (virtual) channels of the next step: sub-kernel nsub_ = (step + 1) / csteps, channel step ncs
-            const int nsub_ = (lasts || NSUB == 1) ? 0 : (step + 1) / csteps;
-            const int ncs = lasts ? 0 : (step + 1) - nsub_ * csteps;
-            if (lasts) loader_setup(n_tblock, n_item < nitems);
+            const int nsub_ = NSUB == 1 ? 0 : nstep / csteps;
+            const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;      // (NSUB == 1: nsteps == csteps)
+            if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
 #pragma unroll
             for (int pl = 0; pl < 16; ++pl) {           // fully unrolled: accumulator and ring indices are static
@@ -283,15 +299,15 @@ void conv_wino_kernel(const ConvParams p) {
             __syncthreads();             // V[cur^1] complete, V[cur] free
             cur ^= 1;
         };
-        step_body(0, std::true_type{});
+        step_body(s0, std::true_type{});
         {   // the next item (its tile table is written here, hidden under this item's MFMAs)
             const bool has_next = n_item < nitems;
-            n_cy = has_next ? n_item / tile_blocks : cy;
-            n_tblock = has_next ? n_item - n_cy * tile_blocks : tblock;
-            table_write(n_tblock, (k + 1) & 1);
+            if (has_next) split_of(n_item, n_kz, n_cy, n_tblock);
+            n_s0 = first_step_of(n_kz);
+            table_write(n_tblock, (k + 1) & 1, n_kz);
             n_wvoff = (n_cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
         }
-        for (int step = 1; step < nsteps; ++step) step_body(step, std::false_type{});
+        for (int step = s0 + 1; step < s1; ++step) step_body(step, std::false_type{});
 
         // ---- epilogue: output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), bias + leaky-ReLU
         //      (+ 2x2 max-pool) + NHWC store.  Nothing else runs on this SIMD meanwhile, so it is kept short and
@@ -325,7 +341,7 @@ void conv_wino_kernel(const ConvParams p) {
 #pragma unroll
                 for (int o = 0; o < 4; ++o) {
                     float x = y[o][q] + bias;
-                    if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                    if (!SPLITK && p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
                     y[o][q] = x;
                 }
             }
@@ -343,6 +359,7 @@ void conv_wino_kernel(const ConvParams p) {
         }
         if (n_item >= nitems) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
+        if (SPLITK) { kz = n_kz; s0 = n_s0; s1 = first_step_of(n_kz + 1); }
     }
 }
 
@@ -384,36 +401,53 @@ void wino_pack_weights(const float* g_hwio /*[k][k][Cin][Cout]*/, int k, int Cin
     }
 }
 
-// mode 1 (auto): only when the grid fills the chip (small problems stay on the direct kernel's small-batch
-// plan); mode 2 (forced, tests): whenever the shape allows.  Returns the tile count of the item shape (32: Cout %
-// 128 == 0, 64: Cout % 64 == 0) or 0.
-int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B) {
+// mode 1 (auto): only when the grid fills the chip -- directly (>= 256 work items) or, for layers without a fused pool,
+// after splitting the channel steps over up to 16 workgroups (small batches: hp3d_posenet2d at B = 1 has 8 .. 128 items
+// per layer); mode 2 (forced, tests): whenever the shape allows.  Returns the tile count of the item shape (32: Cout %
+// 128 == 0, 64: Cout % 64 == 0) or 0; *ksplit (may be NULL) receives the channel split to launch with.
+int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,
+                       int pool, int* ksplit) {
+    if (ksplit) *ksplit = 1;
     if (mode == 0 || (k != 3 && k != 7) || stride != 1 || Cin % 32) return 0;
     const int nt = Cout % 128 == 0 ? 32 : Cout % 64 == 0 ? 64 : 0;
     if (!nt || (k == 3 && nt == 32 && Cin % 64)) return 0;    // at least two steps per item (a 7x7 filter has 9 x Cin/32)
-    // the kernel addresses both tensors with 32-bit offsets (channel strides up to 2x the channel count)
-    if ((long)B * Ho * Wo * (Cin > Cout ? Cin : Cout) * 8 >= (1L << 31)) return 0;
+    // the kernel addresses both tensors with 32-bit byte offsets (stride 1, SAME: input extent = output extent); the
+    // executor sizes its chunks so that the largest layer passes (engine.hip:auto_micro_batch)
+    if ((long)B * Ho * Wo * in_cs * 4 >= (1L << 31) || (long)B * Ho * Wo * out_cs * 4 >= (1L << 31)) return 0;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
     const long items = (tiles + nt - 1) / nt * (Cout / (nt == 32 ? 128 : 64));
-    return (mode == 2 || items >= 256) ? nt : 0;
+    if (items >= 256) return nt;
+    // under-filled: split the channel steps (each split keeps >= 2 steps; partial sums are float32 [ksplit][pix][Cout])
+    const int nsteps = (k == 7 ? 9 : 1) * Cin / (nt == 32 ? 32 : 16);
+    int ks = (int)((256 + items - 1) / items);
+    if (ks > nsteps / 2) ks = nsteps / 2;
+    if (ks > 16) ks = 16;
+    if (!pool && ks >= 2 && ksplit && (long)ks * B * Ho * Wo * Cout * 4 < (1L << 31) && (mode == 2 || items * ks >= 96)) {
+        *ksplit = ks;
+        return nt;
+    }
+    return mode == 2 ? nt : 0;
 }
 
-template <bool POOL, int NT, int NSUB>
+template <bool POOL, int NT, int NSUB, bool SPLITK>
 static void wino_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
     using Cfg = WinoCfg<NT>;
     static bool attr_done[64] = {};
-    auto k = conv_wino_kernel<POOL, NT, NSUB>;
+    auto k = conv_wino_kernel<POOL, NT, NSUB, SPLITK>;
     if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::SMEM_BYTES);
-    const long items = (tiles + NT - 1) / NT * (p.Cout / Cfg::COUTS);
+    const long items = (tiles + NT - 1) / NT * (p.Cout / Cfg::COUTS) * (SPLITK ? p.ksplit : 1);
     const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU (of the current device)
     dim3 grid((unsigned)(items < slots ? items : slots));
     HP3D_LAUNCH(k, grid, dim3(256), Cfg::SMEM_BYTES, s, p);
 }
 
+// pin.ksplit > 1: pin.out must be the partial-sum scratch [ksplit][B*Ho*Wo][Cout] with out_cs = cout_store = Cout; the
+// caller runs conv_splitk_reduce afterwards (bias + activation happen there).
 int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
     // 32-bit byte / element offsets inside the kernel (buffer loads, the tile table)
-    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
+    const long kso = pin.ksplit > 1 ? pin.ksplit : 1;
+    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 31) || kso * pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
     if (pin.nsub != 1 && pin.nsub != 9) return -1;
     ConvParams p = pin;
     p.tiles_x = (p.Wo + 1) / 2;          // Winograd tiles per row / column
@@ -421,12 +455,23 @@ int conv_wino_launch(const ConvParams& pin, int pool, hipStream_t s) {
     const long tiles = (long)p.B * p.tiles_x * p.tiles_y;
     const int nt = p.Cout % 128 == 0 ? 32 : p.Cout % 64 == 0 ? 64 : 0;
     if (!nt || (pool && p.nsub != 1)) return -1;
+    if (p.ksplit > 1) {
+        const int nsteps = p.nsub * p.Cin / (nt == 32 ? 32 : 16);
+        if (pool || p.ksplit * 2 > nsteps || p.out_cs != p.Cout) return -1;
+        if (p.nsub == 9) {
+            if (nt == 32) wino_launch_t<false, 32, 9, true>(p, tiles, s); else wino_launch_t<false, 64, 9, true>(p, tiles, s);
+        } else {
+            if (nt == 32) wino_launch_t<false, 32, 1, true>(p, tiles, s); else wino_launch_t<false, 64, 1, true>(p, tiles, s);
+        }
+        return 0;
+    }
+    p.ksplit = 1;
     if (p.nsub == 9) {
-        if (nt == 32) wino_launch_t<false, 32, 9>(p, tiles, s); else wino_launch_t<false, 64, 9>(p, tiles, s);
+        if (nt == 32) wino_launch_t<false, 32, 9, false>(p, tiles, s); else wino_launch_t<false, 64, 9, false>(p, tiles, s);
     } else if (nt == 32) {
-        if (pool) wino_launch_t<true, 32, 1>(p, tiles, s); else wino_launch_t<false, 32, 1>(p, tiles, s);
+        if (pool) wino_launch_t<true, 32, 1, false>(p, tiles, s); else wino_launch_t<false, 32, 1, false>(p, tiles, s);
     } else {
-        if (pool) wino_launch_t<true, 64, 1>(p, tiles, s); else wino_launch_t<false, 64, 1>(p, tiles, s);
+        if (pool) wino_launch_t<true, 64, 1, false>(p, tiles, s); else wino_launch_t<false, 64, 1, false>(p, tiles, s);
     }
     return 0;
 }

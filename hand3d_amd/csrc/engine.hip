@@ -224,6 +224,10 @@ struct hp3d_ctx {
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
           *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
           *d_pooled = nullptr, *d_fcpart = nullptr;
+    hipStream_t copy_stream = nullptr;   // hp3d_upload_async: H2D of the next batch under the current batch's kernels
+    hipEvent_t upload_done = nullptr;
+    double* d_kpimg = nullptr;   // [B,21,2] float64 (trafo_coords of the detected keypoints)
+    int* d_kpcrop = nullptr;     // [B,21,2] int32 (detect_keypoints: row, col in the crop)
     void* comm = nullptr;        // ncclComm_t (hp3d_comm_init)
     int comm_rank = 0, comm_size = 1;
     int* d_seed = nullptr;
@@ -240,7 +244,9 @@ struct hp3d_ctx {
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
     int use_first = 1;         // conv1_1 on its own kernel (conv_first.hip); conv_impl=direct keeps it on the general one
+    int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_graph = 0;
+    long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
                                // 32 in float32 mode, no split with half-precision trunks -- measured optima)
@@ -386,6 +392,8 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->d_kpmap, (size_t)B * 256 * 256 * 21));
         CHK(dev_realloc(ctx, &ctx->d_pooled, (size_t)B * 32 * 32 * 32));
         CHK(dev_realloc(ctx, &ctx->d_coord, (size_t)B * 63));
+        CHK(dev_realloc(ctx, &ctx->d_kpimg, (size_t)B * 42));
+        CHK(dev_realloc(ctx, &ctx->d_kpcrop, (size_t)B * 42));
         CHK(dev_realloc(ctx, &ctx->d_can, (size_t)B * 63));
         CHK(dev_realloc(ctx, &ctx->d_rot, (size_t)B * 9));
         CHK(dev_realloc(ctx, &ctx->d_u, (size_t)B * 4));
@@ -433,7 +441,9 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
     const double bytes = (f16 ? 2.0 : 4.0) * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
                                 (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
-    if (ctx->use_wino && !f16 && l.ww_off && conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B)) {
+    int wino_ks = 1;
+    if (ctx->use_wino && !f16 && l.ww_off &&
+        conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino_ks : nullptr)) {
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + l.ww_off; p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -441,10 +451,27 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = wino_ks; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = l.k == 7 ? 9 : 1;
-        ProfScope ps(ctx, l.name, l.k == 7 ? "conv_wino_f2x2_3x3_as7x7" : pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
-        if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+        if (wino_ks > 1) {       // under-filled chip: channel steps split over workgroups, raw partial sums, then one reduce
+            const size_t need = (size_t)wino_ks * B * Ho * Wo * l.cout_pad;
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+            p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
+        }
+        {
+            ProfScope ps(ctx, l.name, l.k == 7 ? (wino_ks > 1 ? "conv_wino_f2x2_3x3_as7x7_splitk" : "conv_wino_f2x2_3x3_as7x7")
+                                      : pool ? "conv_wino_f2x2_3x3_pool" : wino_ks > 1 ? "conv_wino_f2x2_3x3_splitk" : "conv_wino_f2x2_3x3", flops, bytes);
+            if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+        }
+        if (wino_ks > 1) {
+            ProfScope ps(ctx, l.name, "conv_splitk_reduce", 0.0, 4.0 * (wino_ks + 1) * B * Ho * Wo * l.cout_pad);
+            conv_splitk_reduce_launch(ctx->col, wino_ks, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                      std::min(l.cout_pad, out_cs), ctx->stream);
+        }
     } else if (l.mode == 1 && !f16 && !pool && ctx->use_first && !ctx->conv_naive &&
                conv_first_eligible(l.k, l.stride, l.cin, l.cout, B, H, W, out_cs)) {
         ConvParams p;
@@ -704,10 +731,24 @@ int run_detect_and_crop(hp3d_ctx* ctx, const float* d_image, int B, int H, int W
     return 0;
 }
 
+// detect_keypoints + trafo_coords (utils/general.py:331-357; run.py:72-73, eval2d.py:93-94) on the 32 x 32 maps of the
+// last PoseNet2D run: no 256 x 256 x 21 heat-map has to exist, let alone travel to the host
+int run_kp_detect(hp3d_ctx* ctx, int B, int32_t* kp_crop, double* kp_image, bool dev) {
+    ProfScope ps(ctx, "kp_detect", "kp_detect", 0.0, 4.0 * B * 32 * 32 * 21);
+    kp_detect_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, ctx->d_scale, ctx->d_center,
+                     dev && kp_crop ? kp_crop : ctx->d_kpcrop, dev && kp_image ? kp_image : ctx->d_kpimg, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    if (!dev) {
+        if (kp_crop) HIPCHK(ctx, hipMemcpyAsync(kp_crop, ctx->d_kpcrop, sizeof(int32_t) * (size_t)B * 42, hipMemcpyDeviceToHost, ctx->stream));
+        if (kp_image) HIPCHK(ctx, hipMemcpyAsync(kp_image, ctx->d_kpimg, sizeof(double) * (size_t)B * 42, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    return 0;
+}
+
 int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                     float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
                     float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
-                    int Win = 0) {
+                    int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
     if (!ctx) return HP3D_ERR_ARG;
     if ((!image && !image_u8) || !hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
     CHK(check_img(ctx, B, H, W));
@@ -737,6 +778,7 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
         ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
         resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, ctx->stream);
     }
+    if (kp_crop || kp_image) CHK(run_kp_detect(ctx, B, kp_crop, kp_image, dev));
     CHK(copy_out(ctx, hand_scoremap, ctx->d_large, (size_t)B * H * W * 2, dev));
     CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, dev));
     CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, dev));
@@ -751,16 +793,30 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
 // Large batches run as consecutive chunks of micro_batch images: per-layer activations of one chunk (<= 0.84 GB at
 // 320x320) stay closer to the caches and every tensor stays inside the 32-bit offsets of the Winograd kernel.  Measured:
 // f32 320x320 B=32 1452 img/s, B=128 unsplit 1355, split 4 x 32 1460; f16 480x640 B=128 unsplit 2316, split 2072 --
-// hence auto = 32 for float32, no split for the half-precision mode.
+// hence auto = at most 32 for float32, no split for the half-precision mode.  The float32 limit also follows the
+// resolution: the largest activation of the path (conv1_1 / conv1_2: H x W x 64 floats per image) must stay below 2^31
+// bytes per chunk or those layers fall off the Winograd kernel (480x640: 27 images), and the chunks are balanced
+// (B = 32 at 480x640 -> 16 + 16, not 27 + 5) so that no chunk under-fills the persistent grids.
+int auto_micro_batch(const hp3d_ctx* ctx, int B, int H, int W) {
+    if (ctx->micro_batch >= 0) return ctx->micro_batch;
+    if (ctx->prec) return 0;
+    const long per_img = (long)H * W * 64 * 4;
+    int lim = (int)std::min<long>(32, ((1L << 31) - 1) / std::max<long>(per_img, 1));
+    if (lim < 1) lim = 1;
+    if (B <= lim) return lim;
+    const int chunks = (B + lim - 1) / lim;
+    return (B + chunks - 1) / chunks;
+}
+
 int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                        float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
                        float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
-                       int Win = 0) {
+                       int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
     if (!ctx) return HP3D_ERR_ARG;
-    const int mb = ctx->micro_batch < 0 ? (ctx->prec ? 0 : 32) : ctx->micro_batch;
+    const int mb = auto_micro_batch(ctx, B, H, W);
     if (mb <= 0 || B <= mb)
         return infer_full_impl(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center, kp_scoremap,
-                               coord3d, hand_mask, dev, image_u8, Hin, Win);
+                               coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image);
     CHK(check_img(ctx, B, H, W));
     if (!hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
     const int saved_prof = ctx->profiling;
@@ -772,7 +828,8 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
         rc = infer_full_impl(ctx, nb, H, W, image ? image + (size_t)b0 * H * W * 3 : nullptr, hand_side + (size_t)b0 * 2,
                              off(hand_scoremap, (size_t)H * W * 2), off(image_crop, 256 * 256 * 3), off(scale_crop, 1),
                              off(center, 2), off(kp_scoremap, 256 * 256 * 21), off(coord3d, 63), off(hand_mask, (size_t)H * W),
-                             dev, image_u8 ? image_u8 + (size_t)b0 * Hin * Win * 3 : nullptr, Hin, Win);
+                             dev, image_u8 ? image_u8 + (size_t)b0 * Hin * Win * 3 : nullptr, Hin, Win,
+                             kp_crop ? kp_crop + (size_t)b0 * 42 : nullptr, kp_image ? kp_image + (size_t)b0 * 42 : nullptr);
     }
     ctx->profiling = saved_prof;
     return rc;
@@ -859,6 +916,7 @@ int run_graphed(hp3d_ctx* ctx, const std::string& key, F&& enqueue) {
     if (g.exec && g.epoch != ctx->graph_epoch) { hipGraphExecDestroy(g.exec); g.exec = nullptr; g.calls = 0; }
     if (g.exec) {
         HIPCHK(ctx, hipGraphLaunch(g.exec, ctx->stream));
+        ++ctx->graph_replays;
         return 0;
     }
     if (g.calls < 0 || g.calls++ == 0) return enqueue();                  // warm-up (or capture failed earlier)
@@ -879,7 +937,9 @@ int run_graphed(hp3d_ctx* ctx, const std::string& key, F&& enqueue) {
     if (ei != hipSuccess) { g.exec = nullptr; g.calls = -1; (void)hipGetLastError(); return enqueue(); }
     g.epoch = ctx->graph_epoch;
     if (getenv("HP3D_GRAPH_DEBUG")) fprintf(stderr, "hp3d graph: captured %s\n", key.c_str());
+    ++ctx->graph_captures;
     HIPCHK(ctx, hipGraphLaunch(g.exec, ctx->stream));
+    ++ctx->graph_replays;
     return 0;
 #endif
 }
@@ -930,6 +990,12 @@ int hp3d_destroy(hp3d_ctx* ctx) {
                     &ctx->d_pooled, &ctx->d_fcpart};
     for (float** p : fp)
         if (*p) hipFree(*p);
+    if (ctx->d_kpimg) hipFree(ctx->d_kpimg);
+#ifndef HP3D_EMU
+    if (ctx->upload_done) hipEventDestroy(ctx->upload_done);
+    if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
+#endif
+    if (ctx->d_kpcrop) hipFree(ctx->d_kpcrop);
 #ifndef HP3D_EMU
     for (auto& kv : ctx->graphs)
         if (kv.second.exec) hipGraphExecDestroy(kv.second.exec);
@@ -956,11 +1022,81 @@ int hp3d_sync(hp3d_ctx* ctx) {
     return 0;
 }
 
+// ---- device / pinned-host memory for callers that hold their batches in HBM (bench.py, dist.py): the C ABI needs no
+//      PyTorch for that.  Copies are ordered on the engine stream (hp3d_memcpy blocks until done); hp3d_upload_async
+//      runs on a second stream so that the H2D of batch n+1 overlaps the kernels of batch n, hp3d_wait_upload makes
+//      the engine stream wait for the last upload.
+int hp3d_dev_alloc(hp3d_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { (void)hipGetLastError(); HP3D_FAIL(ctx, HP3D_ERR_NOMEM, "hipMalloc(%zu) failed", bytes); }
+    *out = p;
+    return 0;
+}
+int hp3d_dev_free(hp3d_ctx* ctx, void* p) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!p) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(p));
+    return 0;
+}
+#ifndef HP3D_EMU
+int hp3d_host_alloc(hp3d_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); HP3D_FAIL(ctx, HP3D_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes); }
+    *out = p;
+    return 0;
+}
+int hp3d_host_free(hp3d_ctx* ctx, void* p) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (p) HIPCHK(ctx, hipHostFree(p));
+    return 0;
+}
+int hp3d_upload_async(hp3d_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx || !dst_dev || !src_host) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (!ctx->copy_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&ctx->upload_done, hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->upload_done, ctx->copy_stream));
+    return 0;
+}
+int hp3d_wait_upload(hp3d_ctx* ctx) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (ctx->upload_done) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->upload_done, 0));
+    return 0;
+}
+#else
+int hp3d_host_alloc(hp3d_ctx* ctx, size_t bytes, void** out) { if (!ctx || !out) return HP3D_ERR_ARG; *out = malloc(bytes ? bytes : 1); return *out ? 0 : HP3D_ERR_NOMEM; }
+int hp3d_host_free(hp3d_ctx* ctx, void* p) { if (!ctx) return HP3D_ERR_ARG; free(p); return 0; }
+int hp3d_upload_async(hp3d_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (!ctx || !dst_dev || !src_host) return HP3D_ERR_ARG;
+    memcpy(dst_dev, src_host, bytes);
+    return 0;
+}
+int hp3d_wait_upload(hp3d_ctx* ctx) { return ctx ? 0 : HP3D_ERR_ARG; }
+#endif
+int hp3d_memcpy(hp3d_ctx* ctx, void* dst, const void* src, size_t bytes, int kind) {
+    if (!ctx || !dst || !src || kind < 0 || kind > 2) return HP3D_ERR_ARG;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHK(ctx, hipMemcpyAsync(dst, src, bytes, k, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (!ctx || !key || !value) return HP3D_ERR_ARG;
     const std::string k(key), v(value);
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
+    if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {
         ctx->conv_naive = (v == "naive");
         ctx->use_wino = (v == "direct" || v == "naive") ? 0 : (v == "winograd") ? 2 : 1;   // mfma = auto
@@ -1171,6 +1307,32 @@ int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, 
     });
 }
 
+int hp3d_infer_full_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                       float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                       float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                       int32_t* keypoint_hw_crop, double* keypoint_hw) {
+    return infer_full_chunked(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                              keypoints_scoremap, keypoint_coord3d, hand_mask, false, nullptr, 0, 0, keypoint_hw_crop, keypoint_hw);
+}
+int hp3d_infer_full_kp_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                           float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                           float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                           int32_t* keypoint_hw_crop, double* keypoint_hw) {
+    if (!ctx) return HP3D_ERR_ARG;
+    return run_graphed(ctx, graph_key("fullkp", {B, H, W}, {image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                                                          keypoints_scoremap, keypoint_coord3d, hand_mask, keypoint_hw_crop, keypoint_hw}), [&]() {
+        return infer_full_chunked(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                                  keypoints_scoremap, keypoint_coord3d, hand_mask, true, nullptr, 0, 0, keypoint_hw_crop, keypoint_hw);
+    });
+}
+int hp3d_infer_full_kp_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* image_u8, int H, int W,
+                          const float* hand_side, float* hand_scoremap, float* image_crop, float* scale_crop,
+                          float* center, float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                          int32_t* keypoint_hw_crop, double* keypoint_hw) {
+    return infer_full_chunked(ctx, B, H, W, nullptr, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                              keypoints_scoremap, keypoint_coord3d, hand_mask, false, image_u8, Hin, Win, keypoint_hw_crop, keypoint_hw);
+}
+
 int hp3d_infer_full_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* image_u8, int H, int W,
                        const float* hand_side, float* hand_scoremap, float* image_crop, float* scale_crop,
                        float* center, float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask) {
@@ -1190,25 +1352,56 @@ int hp3d_preprocess_u8(hp3d_ctx* ctx, const uint8_t* image_u8, int B, int Hin, i
     return finish_op(ctx);
 }
 
-int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
-                  float* image_crop, float* scale_crop, float* center) {
+int hp3d_infer_2d_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
+                     float* image_crop, float* scale_crop, float* center, int32_t* keypoint_hw_crop, double* keypoint_hw) {
     if (!ctx) return HP3D_ERR_ARG;
     if (!image) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image is NULL");
     CHK(check_img(ctx, B, H, W));
     CHK(need_nets(ctx, NET_SEG | NET_POSE));
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    CHK(ensure_arena(ctx, B, H, W));
+    // same chunking as the full path (the float32 Winograd kernels address a chunk with 32-bit offsets)
+    const int mb0 = auto_micro_batch(ctx, B, H, W);
+    const int mb = mb0 <= 0 ? B : std::min(mb0, B);
+    CHK(ensure_arena(ctx, mb, H, W));
+    const int saved_prof = ctx->profiling;
     if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
-    CHK(copy_in(ctx, ctx->d_image, image, (size_t)B * H * W * 3, false));
-    CHK(run_detect_and_crop(ctx, ctx->d_image, B, H, W, 0));
-    CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256));
-    if (keypoints_scoremap) {
-        resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, ctx->d_kpmap, ctx->stream);
-        CHK(copy_out(ctx, keypoints_scoremap, ctx->d_kpmap, (size_t)B * 256 * 256 * 21, false));
+    for (int b0 = 0; b0 < B; b0 += mb) {
+        const int nb = std::min(mb, B - b0);
+        if (b0 > 0 && saved_prof == 1) ctx->profiling = 2;
+        CHK(copy_in(ctx, ctx->d_image, image + (size_t)b0 * H * W * 3, (size_t)nb * H * W * 3, false));
+        CHK(run_detect_and_crop(ctx, ctx->d_image, nb, H, W, 0));
+        CHK(run_posenet(ctx, ctx->d_crop, nb, 256, 256));
+        if (keypoints_scoremap) {
+            resize_bilinear_launch(ctx->d_sm[2], nb, 32, 32, 21, 32, 256, 256, ctx->d_kpmap, ctx->stream);
+            CHK(copy_out(ctx, keypoints_scoremap + (size_t)b0 * 256 * 256 * 21, ctx->d_kpmap, (size_t)nb * 256 * 256 * 21, false));
+        }
+        if (keypoint_hw_crop || keypoint_hw)
+            CHK(run_kp_detect(ctx, nb, keypoint_hw_crop ? keypoint_hw_crop + (size_t)b0 * 42 : nullptr,
+                              keypoint_hw ? keypoint_hw + (size_t)b0 * 42 : nullptr, false));
+        if (image_crop) CHK(copy_out(ctx, image_crop + (size_t)b0 * 256 * 256 * 3, ctx->d_crop, (size_t)nb * 256 * 256 * 3, false));
+        if (scale_crop) CHK(copy_out(ctx, scale_crop + b0, ctx->d_scale, (size_t)nb, false));
+        if (center) CHK(copy_out(ctx, center + (size_t)b0 * 2, ctx->d_center, (size_t)nb * 2, false));
     }
-    CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, false));
-    CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, false));
-    CHK(copy_out(ctx, center, ctx->d_center, (size_t)B * 2, false));
+    ctx->profiling = saved_prof;
+    return finish_op(ctx);
+}
+int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
+                  float* image_crop, float* scale_crop, float* center) {
+    return hp3d_infer_2d_kp(ctx, B, H, W, image, keypoints_scoremap, image_crop, scale_crop, center, nullptr, nullptr);
+}
+
+// hp3d_detect_keypoints: detect_keypoints(tf.image.resize_images(scoremap, (oh, ow))) per image and channel without the
+// large map (utils/general.py:331-344 on the output of CHP3D.py:97); scoremap [B,h,w,C] with h*w <= 4096
+int hp3d_detect_keypoints(hp3d_ctx* ctx, const float* scoremap, int B, int h, int w, int C, int oh, int ow, int32_t* out_rc) {
+    if (!ctx) return HP3D_ERR_ARG;
+    if (!scoremap || !out_rc || B < 1 || h < 1 || w < 1 || C < 1 || oh < 1 || ow < 1 || h * w > 4096)
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments (h*w must be <= 4096)");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    float* d_x = S.upload(scoremap, (size_t)B * h * w * C); NN(ctx, d_x);
+    int* d_o = S.alloc<int>((size_t)B * C * 2); NN(ctx, d_o);
+    kp_detect_launch(d_x, B, h, w, C, C, oh, ow, nullptr, nullptr, d_o, nullptr, ctx->stream);
+    HIPCHK(ctx, hipMemcpyAsync(out_rc, d_o, sizeof(int) * (size_t)B * C * 2, hipMemcpyDeviceToHost, ctx->stream));
     return finish_op(ctx);
 }
 
@@ -1315,7 +1508,8 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
-    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B) && Cout % 64 == 0) {
+    int op_ks = 1;
+    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks : nullptr) && Cout % 64 == 0) {
         const size_t wn = wino_packed_floats(k, l.cin_pad, l.cout_pad);
         std::vector<float> pw(wn + l.cout_pad, 0.f);
         wino_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
@@ -1327,9 +1521,16 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl;
         p.tiles_x = (Wo + 15) / 16; p.tiles_y = (Ho + 7) / 8;
-        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.act = act; p.im2col = 0; p.ksplit = op_ks; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = k == 7 ? 9 : 1;
+        float* d_part = nullptr;
+        if (op_ks > 1) {
+            d_part = S.alloc<float>((size_t)op_ks * B * Ho * Wo * Cout); NN(ctx, d_part);
+            p.out = d_part;
+        }
         if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+        if (op_ks > 1)
+            conv_splitk_reduce_launch(d_part, op_ks, (long)B * Ho * Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
     } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");
         float* d_w = S.upload(w_hwio, (size_t)k * k * Cin * Cout); NN(ctx, d_w);
@@ -1497,6 +1698,13 @@ int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, 
     return 0;
 }
 
+int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
+    if (!ctx || !name || !value) return HP3D_ERR_ARG;
+    const std::string k(name);
+    if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
+    if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
+    HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);
+}
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {
     if (!ctx || !ms_per_stage || n < 1) return HP3D_ERR_ARG;
     float acc[HP3D_TIMING_STAGES] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1622,6 +1830,18 @@ int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
+int hp3d_allgather_dev(hp3d_ctx* ctx, const float* send_dev, int count, float* recv_host) {
+    if (!ctx || !ctx->comm || !send_dev || !recv_host || count < 1) return HP3D_ERR_ARG;
+    Rccl* R = rccl(ctx);
+    if (!R) return HP3D_ERR_UNSUPPORTED;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    Scratch S(ctx);
+    float* d_recv = S.alloc<float>((size_t)count * ctx->comm_size); NN(ctx, d_recv);
+    NCCLCHK(ctx, R, R->AllGather(send_dev, d_recv, (size_t)count, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(recv_host, d_recv, sizeof(float) * count * ctx->comm_size, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 int hp3d_comm_destroy(hp3d_ctx* ctx) {
     if (!ctx) return HP3D_ERR_ARG;
     if (!ctx->comm) return 0;
@@ -1635,6 +1855,7 @@ int hp3d_comm_unique_id(void*) { return HP3D_ERR_UNSUPPORTED; }
 int hp3d_comm_init(hp3d_ctx* ctx, int, int, const void*) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
 int hp3d_bcast_weights(hp3d_ctx* ctx, int) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
 int hp3d_allgather(hp3d_ctx* ctx, const float*, int, float*) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
+int hp3d_allgather_dev(hp3d_ctx* ctx, const float*, int, float*) { HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "no RCCL in the CPU interpreter build"); }
 int hp3d_comm_destroy(hp3d_ctx*) { return 0; }
 #endif
 

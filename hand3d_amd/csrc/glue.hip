@@ -586,6 +586,56 @@ void argmax2d_kernel(const float* x, int H, int W, int C, int cs, int* out_rc) {
     }
 }
 
+// detect_keypoints + trafo_coords (utils/general.py:331-357) WITHOUT the 256 x 256 x 21 map in HBM: one workgroup per
+// (channel, image) holds the h x w score map of its channel in LDS, evaluates tf.image.resize_images' arithmetic
+// (resize_bilinear_kernel above, op for op) for every pixel of the oh x ow map and keeps the FIRST maximum in row-major
+// order -- exactly np.argmax of the up-sampled map, ties and rounding included (the maximum of the small map times the
+// up-sampling factor is NOT always it: a neighbour 1 ulp below the peak can round up to the peak value at an earlier
+// interpolated position).  kp_crop [B,C,2] int32 (row, col); kp_image [B,C,2] float64 =
+// (kp - crop_size // 2) / scale + center evaluated in double like NumPy does on float64 keypoints and float32 scale / centre.
+HP3D_KERNEL(256)
+void kp_detect_kernel(const float* sm, int h, int w, int C, int cs, int oh, int ow, const float* scale,
+                      const float* center, int* kp_crop, double* kp_image) {
+    __shared__ float src[64 * 64];
+    __shared__ unsigned long long red[4];
+    const int c = blockIdx.x, b = blockIdx.y;
+    const float* xb = sm + (size_t)b * h * w * cs + c;
+    for (int i = threadIdx.x; i < h * w; i += blockDim.x) src[i] = xb[(size_t)i * cs];
+    __syncthreads();
+    const float hscale = (float)h / (float)oh, wscale = (float)w / (float)ow;
+    unsigned long long best = 0ull;
+    for (int oy = threadIdx.x; oy < oh; oy += blockDim.x) {
+        int y0, y1; float ty;
+        resize_coord(oy, hscale, h, y0, y1, ty);
+        for (int ox = 0; ox < ow; ++ox) {
+            int x0, x1; float tx;
+            resize_coord(ox, wscale, w, x0, x1, tx);
+            const float tl = src[y0 * w + x0], tr = src[y0 * w + x1], bl = src[y1 * w + x0], br = src[y1 * w + x1];
+            const float top = tl + (tr - tl) * tx;
+            const float bot = bl + (br - bl) * tx;
+            const float v = top + (bot - top) * ty;
+            const unsigned long long key = ((unsigned long long)ord_f32(v) << 32) |
+                                           (unsigned long long)(0xFFFFFFFFu - (unsigned)(oy * ow + ox));
+            best = key > best ? key : best;
+        }
+    }
+    best = wave_max_u64(best);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) best = red[i] > best ? red[i] : best;
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+        const int row = (int)(idx / (unsigned)ow), col = (int)(idx % (unsigned)ow);
+        const size_t o = ((size_t)b * C + c) * 2;
+        if (kp_crop) { kp_crop[o] = row; kp_crop[o + 1] = col; }
+        if (kp_image) {
+            const double sc = (double)scale[b];
+            kp_image[o] = ((double)row - (double)(oh / 2)) / sc + (double)center[b * 2];
+            kp_image[o + 1] = ((double)col - (double)(ow / 2)) / sc + (double)center[b * 2 + 1];
+        }
+    }
+}
+
 inline int grid_for(long total, int block = 256, int cap = 256 * 16) {
     long g = (total + block - 1) / block;
     if (g < 1) g = 1;
@@ -687,6 +737,10 @@ void lift_epilogue_launch(const float* u, const float* coord_can, const float* h
 }
 void bone_rel_inv_launch(const float* rel, int B, float* xyz, hipStream_t s) {
     HP3D_LAUNCH(bone_rel_inv_kernel, dim3((B + 63) / 64), dim3(64), 0, s, rel, B, xyz);
+}
+void kp_detect_launch(const float* sm, int B, int h, int w, int C, int cs, int oh, int ow, const float* scale,
+                      const float* center, int* kp_crop, double* kp_image, hipStream_t s) {
+    HP3D_LAUNCH(kp_detect_kernel, dim3(C, B), dim3(256), 0, s, sm, h, w, C, cs, oh, ow, scale, center, kp_crop, kp_image);
 }
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s) {
     HP3D_LAUNCH(argmax2d_kernel, dim3(C, B), dim3(256), 0, s, x, H, W, C, cs, out_rc);

@@ -72,12 +72,16 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
+// 16 B per lane (same addressing / range check)
+#define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, (val4)), (rsrc), (voff), (soff), 0)
 #else
 typedef int hp3d_rsrc_t;
 #define HP3D_MAKE_RSRC(ptr, bytes) 0
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
 #endif
 #endif
@@ -126,7 +130,8 @@ const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& 
 void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs);
 int conv_first_launch(const ConvParams& p, hipStream_t s);
-int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B);
+int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,
+                       int pool, int* ksplit);
 size_t wino_packed_floats(int k, int cin_pad, int cout_pad);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
@@ -166,6 +171,9 @@ void concat_handside_launch(const float* feat, int B, int F, const float* hand_s
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B,
                           float* rot, float* coord_rel, int do_flip_rot, hipStream_t s);
 void bone_rel_inv_launch(const float* rel, int B, float* xyz, hipStream_t s);   // [B,21,3] local -> xyz
+// first arg-max of the up-sampled (oh x ow, legacy bilinear) score map per channel + trafo_coords; h*w <= 4096
+void kp_detect_launch(const float* sm, int B, int h, int w, int C, int cs, int oh, int ow, const float* scale,
+                      const float* center, int* kp_crop, double* kp_image, hipStream_t s);
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s);
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s);
 void cvt_channels_f16_launch(const float* in, int npix, int C, int in_cs, hp3d_f16* out, int out_cs, hipStream_t s);

@@ -1,10 +1,24 @@
-"""Batch sharding across the GPUs of one node: every image is independent, so
-the path shards with NO data-path collective.  torch.distributed (backend "nccl" == RCCL over
-xGMI; "gloo" in the CPU tests) is used as plumbing for two tiny exchanges only:
-  * once: broadcast of the packed weight blob (468 MB: direct + Winograd-domain filters + f16 section) from rank 0;
-  * per batch: gather of the [B/n,21,3] keypoints (252 B/image).
+"""Batch sharding across the GPUs of one node: every image is independent, so the path shards with NO
+data-path collective.  Two tiny exchanges remain, both RCCL over xGMI on the engine's own stream through the C ABI
+(include/hp3d.h: hp3d_comm_init / hp3d_bcast_weights / hp3d_allgather[_dev]):
+  * once: broadcast of the packed weight blob from rank 0;
+  * per batch: all-gather of the [B/n,21,3] keypoints (252 B/image).
 The reference has no counterpart (single tf.Session everywhere, run.py:50).
+
+No PyTorch is needed: one process per GPU is started by any launcher that exports RANK / WORLD_SIZE / LOCAL_RANK /
+MASTER_ADDR / MASTER_PORT (torch.distributed.run does; so does a shell loop), and the only thing the processes have to
+agree on before RCCL exists -- the 128-byte communicator id -- travels over a plain TCP socket (`Rendezvous`), which
+also carries the host-side scalars of the benchmark protocol (barrier, max of the per-rank wall times).
+
+The torch.distributed helpers at the bottom (`broadcast_blob`, `gather_keypoints`) remain for callers that already
+live inside a torch process group (and for the gloo CPU test); nothing in the product path imports torch.
 """
+import os
+import pickle
+import socket
+import struct
+import time
+
 import numpy as np
 
 
@@ -19,8 +33,210 @@ def shard_sizes(n_items, world):
     return [shard_range(n_items, r, world)[1] - shard_range(n_items, r, world)[0] for r in range(world)]
 
 
+# ------------------------------------------------------------------------------------------- TCP rendezvous
+_MAGIC = b'HP3DRDZV1'
+
+
+def _send_msg(sock, obj):
+    data = pickle.dumps(obj, protocol=4)
+    sock.sendall(struct.pack('<Q', len(data)) + data)
+
+
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("rendezvous peer closed the connection")
+        buf += chunk
+    return bytes(buf)
+
+
+def _recv_msg(sock):
+    (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
+    return pickle.loads(_recv_exact(sock, n))
+
+
+def rendezvous_ports(master_port):
+    """The launcher's own store listens on MASTER_PORT; the rendezvous takes the first free port of a fixed sequence
+    derived from it (every rank walks the same sequence; a handshake tells a foreign listener from rank 0)."""
+    base = int(master_port)
+    return [1024 + (base - 1024 + 977 + 131 * k) % (65536 - 1024) for k in range(8)]
+
+
+class Rendezvous(object):
+    """Star over TCP with rank 0 as the hub: allgather / broadcast / barrier of small Python objects.  World size 1
+    needs no socket.  Single node, trusted peers (the launcher's processes): pickle is used for the payload."""
+
+    def __init__(self, rank, world, addr='127.0.0.1', port=29500, timeout=300.0, token=None):
+        self.rank, self.world = int(rank), int(world)
+        self.peers = {}          # hub: rank -> socket
+        self.sock = None         # spoke: socket to the hub
+        self.token = (token if token is not None else '%s:%d' % (port, self.world))
+        if self.world == 1:
+            return
+        ports = rendezvous_ports(port)
+        deadline = time.time() + timeout
+        if self.rank == 0:
+            srv = None
+            for p in ports:
+                try:
+                    srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                    srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                    srv.bind((addr, p))
+                    break
+                except OSError:
+                    srv.close()
+                    srv = None
+            if srv is None:
+                raise RuntimeError("rendezvous: none of the ports %s could be bound on %s" % (ports, addr))
+            srv.listen(self.world)
+            srv.settimeout(1.0)
+            while len(self.peers) < self.world - 1:
+                if time.time() > deadline:
+                    raise TimeoutError("rendezvous: %d of %d ranks joined" % (len(self.peers) + 1, self.world))
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    c.settimeout(10.0)
+                    hello = _recv_exact(c, len(_MAGIC))
+                    msg = _recv_msg(c) if hello == _MAGIC else None
+                    if not msg or msg.get('token') != self.token or not (0 < msg.get('rank', 0) < self.world) \
+                            or msg['rank'] in self.peers:
+                        c.close()
+                        continue
+                    c.sendall(_MAGIC)
+                    c.settimeout(timeout)
+                    c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.peers[msg['rank']] = c
+                except (OSError, ConnectionError, pickle.UnpicklingError, EOFError):
+                    c.close()
+            srv.close()
+        else:
+            k = 0
+            while self.sock is None:
+                if time.time() > deadline:
+                    raise TimeoutError("rendezvous: rank %d could not reach rank 0 on %s ports %s" % (self.rank, addr, ports))
+                p = ports[k % len(ports)]
+                k += 1
+                try:
+                    s = socket.create_connection((addr, p), timeout=2.0)
+                    s.settimeout(10.0)
+                    s.sendall(_MAGIC)
+                    _send_msg(s, {'token': self.token, 'rank': self.rank})
+                    if _recv_exact(s, len(_MAGIC)) != _MAGIC:
+                        raise ConnectionError("not a rendezvous hub")
+                    s.settimeout(timeout)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    self.sock = s
+                except (OSError, ConnectionError):
+                    try:
+                        s.close()
+                    except Exception:
+                        pass
+                    if k % len(ports) == 0:
+                        time.sleep(0.2)
+
+    @classmethod
+    def from_env(cls, timeout=300.0):
+        return cls(int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')),
+                   os.environ.get('MASTER_ADDR', '127.0.0.1'), int(os.environ.get('MASTER_PORT', '29500')), timeout)
+
+    def allgather(self, obj):
+        """[obj of rank 0, ..., obj of rank world-1] on every rank."""
+        if self.world == 1:
+            return [obj]
+        if self.rank == 0:
+            objs = [obj] + [None] * (self.world - 1)
+            for r, s in self.peers.items():
+                objs[r] = _recv_msg(s)
+            for s in self.peers.values():
+                _send_msg(s, objs)
+            return objs
+        _send_msg(self.sock, obj)
+        return _recv_msg(self.sock)
+
+    def broadcast(self, obj, src=0):
+        return self.allgather(obj if self.rank == src else None)[src]
+
+    def barrier(self):
+        self.allgather(None)
+
+    def max(self, x):
+        return max(self.allgather(float(x)))
+
+    def close(self):
+        for s in list(self.peers.values()) + ([self.sock] if self.sock else []):
+            try:
+                s.close()
+            except Exception:
+                pass
+        self.peers, self.sock = {}, None
+
+
+# ------------------------------------------------------------------------------------------- native (RCCL via the C ABI)
+class ShardedPipeline(object):
+    """One rank's share of a sharded batch: the engine, its RCCL communicator and the rendezvous that set it up.
+    `weights` is needed on rank 0 only."""
+
+    def __init__(self, engine, rank=0, world=1, rdzv=None):
+        self.engine, self.rank, self.world = engine, int(rank), int(world)
+        self.rdzv = rdzv if rdzv is not None else Rendezvous(rank, world) if world == 1 else None
+        if self.rdzv is None:
+            raise ValueError("world > 1 needs a Rendezvous (Rendezvous.from_env())")
+        self.comm_ready = False
+
+    def comm_init(self):
+        """hp3d_comm_init on every rank: rank 0 draws the 128-byte id, the rendezvous hands it round."""
+        if not self.comm_ready:
+            uid = self.rdzv.broadcast(self.engine.comm_unique_id() if self.rank == 0 else None, 0)
+            self.engine.comm_init(self.rank, self.world, uid)
+            self.comm_ready = True
+
+    def sync_weights(self, weights=None, dtype=0, use_comm=None):
+        """Rank 0 packs the weight dictionary; every other rank receives the packed device blob (and rank 0's nets mask
+        and precision) by hp3d_bcast_weights -- no un-pickling or re-packing on the other ranks.  use_comm: None = only
+        when world > 1; True forces the RCCL path at world size 1 as well (hardware smoke test of the exchange)."""
+        if self.rank == 0:
+            self.engine.load_weight_dict(weights)
+            self.engine.finalize_weights(dtype)
+        if use_comm or (use_comm is None and self.world > 1):
+            self.comm_init()
+            self.engine.bcast_weights(0)
+
+    sync_weights_native = sync_weights        # round-1 name
+
+    def gather_keypoints(self, coord_dev, n_local):
+        """hp3d_allgather_dev of this rank's [n_local,21,3] device-resident keypoints -> float32 [world*n_local,21,3]
+        on the host of every rank (equal shard sizes: the benchmark's weak-scaling layout)."""
+        if self.world == 1 and not self.comm_ready:
+            return self.engine.to_host(coord_dev, (n_local, 21, 3))
+        return self.engine.allgather_dev(coord_dev, n_local * 63, self.world).reshape(self.world * n_local, 21, 3)
+
+    def gather_ragged(self, local_kp, n_total):
+        """Ragged shards (shard_range): pad to the largest shard, hp3d_allgather, cut the padding."""
+        sizes = shard_sizes(n_total, self.world)
+        mx = max(sizes)
+        pad = np.zeros((mx,) + tuple(local_kp.shape[1:]), np.float32)
+        pad[:local_kp.shape[0]] = local_kp
+        if self.world == 1 and not self.comm_ready:
+            return pad[:sizes[0]]
+        full = self.engine.allgather(pad, self.world).reshape((self.world, mx) + tuple(local_kp.shape[1:]))
+        return np.concatenate([full[r, :s] for r, s in enumerate(sizes)], 0)
+
+    def close(self):
+        if self.comm_ready:
+            self.engine.comm_destroy()
+            self.comm_ready = False
+        self.rdzv.close()
+
+
+# ------------------------------------------------------------------------------------------- torch.distributed variants
 def broadcast_blob(blob_tensor, src=0, group=None):
-    """In-place broadcast of the packed weight blob (a flat torch tensor on the rank's device)."""
+    """In-place broadcast of the packed weight blob (a flat torch tensor on the rank's device) inside an existing
+    torch process group."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():
         dist.broadcast(blob_tensor, src=src, group=group)
@@ -28,8 +244,8 @@ def broadcast_blob(blob_tensor, src=0, group=None):
 
 
 def gather_keypoints(local_kp, n_total=None, group=None):
-    """all_gather of per-rank keypoints [b_r,21,3] -> [sum b_r,21,3] in rank order (every rank gets
-    the result; rank 0 is the consumer).  Ragged shards are padded to the largest shard."""
+    """all_gather of per-rank keypoints [b_r,21,3] (torch tensors) -> [sum b_r,21,3] in rank order.  Ragged shards are
+    padded to the largest shard."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
@@ -50,48 +266,25 @@ def gather_keypoints(local_kp, n_total=None, group=None):
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], 0)
 
 
-def native_comm_init(engine, rank, world, group=None):
-    """Set up the engine's own RCCL communicator (include/hp3d.h hp3d_comm_*): rank 0 draws the 128-byte id, the
-    launcher's process group (any backend) only carries those bytes to the other ranks."""
+def sync_weights_torch(engine, rank, world, weights=None, device=None, dtype=0, group=None):
+    """The weight exchange through torch.distributed (backend nccl = RCCL) for callers inside a torch process group:
+    hp3d_weights_blob_export -> dist.broadcast -> hp3d_weights_blob_import, with rank 0's real nets mask."""
+    import torch
     import torch.distributed as dist
-    ids = [engine.comm_unique_id() if rank == 0 else None]
-    if world > 1:
-        dist.broadcast_object_list(ids, src=0, group=group)
-    engine.comm_init(rank, world, ids[0])
-
-
-class ShardedPipeline(object):
-    """One rank's share of a sharded batch: engine + device-resident I/O (torch tensors are used
-    only as device memory).  `weights` is needed on rank 0 only."""
-
-    def __init__(self, engine, rank=0, world=1, group=None):
-        self.engine, self.rank, self.world, self.group = engine, rank, world, group
-
-    def sync_weights_native(self, weights=None, dtype=0):
-        """Same as sync_weights through the C ABI only: hp3d_comm_init + hp3d_bcast_weights (RCCL on the engine's
-        stream, no torch tensors)."""
-        if self.rank == 0:
-            self.engine.load_weight_dict(weights)
-            self.engine.finalize_weights(dtype)
-        native_comm_init(self.engine, self.rank, self.world, self.group)
-        self.engine.bcast_weights(0)
-
-    def sync_weights(self, weights=None, device=None, dtype=0):
-        import torch
-        from . import _lib
-        full = _lib.NET_SEG | _lib.NET_POSE | _lib.NET_PRIOR | _lib.NET_VP | (32 if dtype in (1, 'f16') else 0)
-        if self.rank == 0:
-            self.engine.load_weight_dict(weights)
-            self.engine.finalize_weights(dtype)
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        n = (self.engine.blob_bytes() + 3) // 4
-        blob = torch.empty(n, dtype=torch.float32, device=device)
-        if self.rank == 0:
-            self.engine.blob_export(blob.data_ptr())
-        broadcast_blob(blob, 0, self.group)
+    if rank == 0:
+        engine.load_weight_dict(weights)
+        engine.finalize_weights(dtype)
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    mask = torch.tensor([engine.nets_mask() if rank == 0 else 0], dtype=torch.int64, device=device)
+    dist.broadcast(mask, src=0, group=group)
+    n = (engine.blob_bytes() + 3) // 4
+    blob = torch.empty(n, dtype=torch.float32, device=device)
+    if rank == 0:
+        engine.blob_export(blob.data_ptr())
+    broadcast_blob(blob, 0, group)
+    if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
         torch.cuda.synchronize(device)
-        if self.rank != 0 or self.world == 1:     # world 1 (torchrun with one rank) re-imports its own blob: exercises the path
-            self.engine.blob_import(blob.data_ptr(), full)
-        del blob
+    if rank != 0 or world == 1:
+        engine.blob_import(blob.data_ptr(), int(mask.item()))
+    del blob

@@ -80,6 +80,22 @@ class ColorHandPose3DNetwork(object):
         o = self.engine.infer_full_u8(image_u8, hand_side, net_size[0], net_size[1])
         return o['scoremap'], o['crop'], o['scale'], o['center'], o['kpmap'], o['coord3d']
 
+    def inference_keypoints(self, image, hand_side, evaluation):
+        """ Not in the reference class: inference() followed by the scripts' host post-processing
+            (run.py:72-73: detect_keypoints + trafo_coords, utils/general.py:331-357) evaluated on the device, so
+            neither the 5.5 MB/image heat-maps nor the crop travel to the host.  Returns
+            keypoint_coord3d [B,21,3] float32, keypoint_hw [B,21,2] float64 (row, col in the input image),
+            keypoint_hw_crop [B,21,2] float64 (row, col in the 256x256 crop), scale_crop [B,1], center [B,2]. """
+        self._check_eval(evaluation)
+        o = self.engine.infer_full(image, hand_side, outputs=('coord3d', 'kp_crop', 'kp_hw', 'scale', 'center'))
+        return o['coord3d'], o['kp_hw'], o['kp_crop'].astype(np.float64), o['scale'], o['center']
+
+    def inference2d_keypoints(self, image):
+        """ inference2d() + detect_keypoints + trafo_coords on the device (eval2d.py:58,93-94): keypoint_hw [B,21,2]
+            float64 in the input image, keypoint_hw_crop [B,21,2] float64, scale_crop, center. """
+        kpc, kph, scale, center = self.engine.infer_2d_keypoints(image)
+        return kph, kpc.astype(np.float64), scale, center
+
     def inference2d(self, image):
         """ Only 2D part of the pipeline: HandSegNet + PoseNet (reference :101-129).
             Returns keypoints_scoremap, image_crop, scale_crop, center -- note the order. """

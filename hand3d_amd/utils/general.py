@@ -8,6 +8,8 @@ calc_auc :654-659.  Written from the behaviour (vectorised NumPy), not from the 
 """
 import numpy as np
 
+_trapz = getattr(np, 'trapezoid', None) or np.trapz          # NumPy >= 2.0 renamed trapz (the reference calls np.trapz)
+
 
 def detect_keypoints(scoremaps):
     """[H,W,C] (or [1,H,W,C]) score maps -> float64 [C,2] with (v=row, u=col) of each channel's first maximum."""
@@ -53,14 +55,14 @@ class EvalUtil:
     def get_measures(self, val_min, val_max, steps):
         """(mean EPE, median EPE, AUC, PCK curve, thresholds): each averaged over keypoints that have data."""
         thresholds = np.linspace(val_min, val_max, steps)
-        width = np.trapezoid(np.ones_like(thresholds), thresholds)
+        width = _trapz(np.ones_like(thresholds), thresholds)
         errs = self._errors()
         pck = np.array([[np.mean(e <= t) for t in thresholds] for e in errs])       # [keypoints with data, steps]
-        auc = np.array([np.trapezoid(row, thresholds) / width for row in pck])
+        auc = np.array([_trapz(row, thresholds) / width for row in pck])
         return (np.mean([e.mean() for e in errs]), np.mean([np.median(e) for e in errs]), np.mean(auc),
                 pck.mean(axis=0), thresholds)
 
 
 def calc_auc(x, y):
     """Normalised area under the curve y(x)."""
-    return np.trapezoid(y, x) / np.trapezoid(np.ones_like(y), x)
+    return _trapz(y, x) / _trapz(np.ones_like(y), x)

@@ -201,11 +201,14 @@ def read_index(index_path, verify=True):
     return entries, num_shards
 
 
-def read_bundle(prefix, verify=True):
-    """All tensors of the checkpoint <prefix>(.index, .data-*) as {name: ndarray}."""
+def read_bundle(prefix, verify=True, keep=None):
+    """Tensors of the checkpoint <prefix>(.index, .data-*) as {name: ndarray}; `keep(name) -> bool` selects which entries
+    are read at all (the others are neither decoded nor checksummed, whatever their dtype)."""
     entries, num_shards = read_index(prefix + '.index', verify)
     shards, out = {}, {}
     for name, e in entries.items():
+        if keep is not None and not keep(name):
+            continue
         if e['slices']:
             raise NotImplementedError("partitioned variable %s (tensor slices) is not supported" % name)
         if e['dtype'] not in _DTYPES:
@@ -228,11 +231,11 @@ def load_weights_from_snapshot(checkpoint_path, discard_list=None, rename_dict=N
     """The selection / renaming of utils/general.py:614-651 on a V2 checkpoint prefix -> {name: ndarray}.
     A variable is dropped if ANY discard string occurs in its name; every rename key that occurs in the name is
     replaced (in dict order, on the progressively renamed name -- exactly the reference's loop)."""
-    tensors = read_bundle(checkpoint_path)
+    # only the surviving variables are touched, like the reference (reader.get_tensor runs after the discard loop,
+    # :619-646): optimiser slots or non-float bookkeeping entries in the discard list are never decoded
+    tensors = read_bundle(checkpoint_path, keep=lambda n: discard_list is None or not any(d in n for d in discard_list))
     out = {}
     for name, value in tensors.items():
-        if discard_list is not None and any(d in name for d in discard_list):
-            continue
         new_name = name
         if rename_dict is not None:
             for k, v in rename_dict.items():

@@ -61,8 +61,11 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            fills the chip, >= 256 work items) | "direct" (never Winograd: bit-identical to an fmaf
  *                            chain) | "winograd" (whenever the shape allows; per-op hp3d_conv2d then refuses other
  *                            shapes) | "naive" (debug cross-check kernel, never a fallback);
+ *          "wino_splitk"  = "1" (default) | "0": Winograd layers whose work items under-fill the chip (small batches) split
+ *                            their channel steps over up to 16 workgroups and sum float32 partials in a fixed order;
  *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N
- *                            images ("0" = never split; default "auto" = 32 in float32 mode, no split with f16 trunks).
+ *                            images ("0" = never split; default "auto" = at most 32 in float32 mode -- fewer when H x W x 64 floats x N
+ *                            would pass 2^31 bytes, e.g. 480x640: balanced chunks of <= 27 -- and no split with f16 trunks).
  *                            Bit-identical to making the calls chunk by chunk;
  *          "graph"        = "0" | "1": the device-pointer entry points (hp3d_infer_full_dev, hp3d_posenet2d_dev) replay
  *                            their launch sequence as one hipGraph from the third identical call on (same shape and
@@ -113,6 +116,24 @@ int hp3d_infer_full(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
 int hp3d_infer_full_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                         float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
                         float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask);
+/* The same calls with the host post-processing of the scripts done on the device (run.py:72-73, eval2d.py:93-94,
+ * eval2d_gt_cropped.py:76): keypoint_hw_crop [B,21,2] int32 = detect_keypoints(keypoints_scoremap[b])
+ * (utils/general.py:331-344: per channel the first maximum, (row, col)) and keypoint_hw [B,21,2] float64 =
+ * trafo_coords(keypoint_hw_crop, center, scale_crop, 256) (utils/general.py:347-357).  Computed from the 32x32 maps
+ * by re-evaluating tf.image.resize_images' arithmetic, so keypoints_scoremap (5.5 MB / image) may be NULL: eval loops
+ * need no heat-map copy.  Bit-exact with the reference functions applied to the up-sampled map, ties included.      */
+int hp3d_infer_full_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                       float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                       float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                       int32_t* keypoint_hw_crop, double* keypoint_hw);
+int hp3d_infer_full_kp_dev(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                           float* hand_scoremap, float* image_crop, float* scale_crop, float* center,
+                           float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                           int32_t* keypoint_hw_crop, double* keypoint_hw);
+int hp3d_infer_full_kp_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* image_u8, int H, int W,
+                          const float* hand_side, float* hand_scoremap, float* image_crop, float* scale_crop,
+                          float* center, float* keypoints_scoremap, float* keypoint_coord3d, float* hand_mask,
+                          int32_t* keypoint_hw_crop, double* keypoint_hw);
 /* SURVEY.md 8f N2 -- the step immediately before the hot path, on device: uint8 frames
  * [B,Hin,Win,3] -> x/255-0.5 (data/BinaryDbReader.py:182, run.py:59) -> tf.image.resize_images to H x W
  * (eval_full.py:50, eval2d.py:53; equal sizes = identity) -> hp3d_infer_full.  4x less H2D traffic.      */
@@ -122,6 +143,9 @@ int hp3d_infer_full_u8(hp3d_ctx* ctx, int B, int Hin, int Win, const uint8_t* im
 int hp3d_preprocess_u8(hp3d_ctx* ctx, const uint8_t* image_u8, int B, int Hin, int Win, int H, int W, float* out);
 int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image,
                   float* keypoints_scoremap, float* image_crop, float* scale_crop, float* center);
+int hp3d_infer_2d_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,
+                     float* image_crop, float* scale_crop, float* center,
+                     int32_t* keypoint_hw_crop, double* keypoint_hw);   /* + detect_keypoints / trafo_coords, as above */
 int hp3d_handsegnet(hp3d_ctx* ctx, int B, int H, int W, const float* image,
                     float* scoremap_large, float* scoremap_small);
 int hp3d_posenet2d(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop,
@@ -159,6 +183,10 @@ int hp3d_mask_from_scoremap(hp3d_ctx* ctx, const float* scoremap, int B, int H, 
 int hp3d_fc(hp3d_ctx* ctx, const float* x, int B, int Cin, const float* w, const float* bias,
             int Cout, int act, float* out);
 int hp3d_argmax2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int C, int32_t* out_rc);
+/* detect_keypoints(tf.image.resize_images(scoremap, (out_h, out_w))[b]) for scoremap [B,h,w,C], h*w <= 4096, without
+ * materialising the large map (utils/general.py:331-344 applied to nets/ColorHandPose3DNetwork.py:97): out_rc [B,C,2] */
+int hp3d_detect_keypoints(hp3d_ctx* ctx, const float* scoremap, int B, int h, int w, int C, int out_h, int out_w,
+                          int32_t* out_rc);
 
 /* ---- measurement ------------------------------------------------------------------------
  * With profiling on (1: last whole-path call only, 2: accumulate over calls until switched off),
@@ -173,6 +201,9 @@ int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, 
  * lifting epilogue, [4] everything.  Writes min(n, 5) values; needs hp3d_set_profiling(ctx, 1 | 2).  */
 #define HP3D_TIMING_STAGES 5
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
+/* Executor counters: "graph_captures" / "graph_replays" = hipGraphs instantiated / launched since hp3d_create (option
+ * "graph" = "1"; a replay happens only with per-launch profiling off).                                            */
+int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);
 
 /* ---- multi-GPU: one process and one context per GPU, RCCL over xGMI ---------
  * The path has no data-path collective.  These are the two exchanges it needs, on the context's own stream:
@@ -186,7 +217,21 @@ int hp3d_comm_unique_id(void* id128);
 int hp3d_comm_init(hp3d_ctx* ctx, int rank, int nranks, const void* id128);
 int hp3d_bcast_weights(hp3d_ctx* ctx, int root);
 int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv_host /* [nranks * count] */);
+int hp3d_allgather_dev(hp3d_ctx* ctx, const float* send_dev, int count, float* recv_host /* [nranks * count] */);
 int hp3d_comm_destroy(hp3d_ctx* ctx);
+
+/* ---- memory for callers that keep their batches in HBM (the `_dev` entry points; bench.py, hand3d_amd/dist.py) ---
+ * Replaces what the reference left to TensorFlow's feed_dict / allocator (run.py:61-64): device buffers, pinned host
+ * buffers, blocking copies ordered on the context's stream (kind 0 = host->device, 1 = device->host, 2 = device->
+ * device), and an upload on a SECOND stream so that the host->device copy of batch n+1 runs under the kernels of
+ * batch n (hp3d_wait_upload makes the compute stream wait for the last hp3d_upload_async).  No PyTorch needed.     */
+int hp3d_dev_alloc(hp3d_ctx* ctx, size_t bytes, void** out);
+int hp3d_dev_free(hp3d_ctx* ctx, void* p);
+int hp3d_host_alloc(hp3d_ctx* ctx, size_t bytes, void** out);      /* page-locked */
+int hp3d_host_free(hp3d_ctx* ctx, void* p);
+int hp3d_memcpy(hp3d_ctx* ctx, void* dst, const void* src, size_t bytes, int kind);
+int hp3d_upload_async(hp3d_ctx* ctx, void* dst_dev, const void* src_pinned_host, size_t bytes);
+int hp3d_wait_upload(hp3d_ctx* ctx);
 
 /* ---- host utility ----------------------------------------------------------------------------
  * CRC-32C (Castagnoli) of a host buffer: the checksum TensorFlow checkpoints carry (hand3d_amd/utils/tf_checkpoint.py

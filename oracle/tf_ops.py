@@ -9,6 +9,11 @@ import numpy as np
 
 F32 = np.float32
 
+# How conv2d_same / fully_connected contract in float32: 'numpy' = tap-by-tap GEMMs on NumPy's BLAS (default; the form
+# every parity test uses), 'torch' = torch.nn.functional.conv2d on the CPU (oneDNN, all cores) with the same explicit TF
+# SAME padding -- the "CPU restatement baseline" of SURVEY.md 8d that bench.py times (cpu_baseline, kind "port").
+CONV_BACKEND = 'numpy'
+
 
 # --------------------------------------------------------------------------- conv
 def same_pads(in_size, k, stride):
@@ -30,6 +35,14 @@ def conv2d_same(x, w, stride=1, acc=np.float32):
     assert k == k2 and Cin2 == Cin
     Ho, pt, pb = same_pads(H, k, stride)
     Wo, pl, pr = same_pads(W, k, stride)
+    if CONV_BACKEND == 'torch' and acc == np.float32:
+        import torch
+        import torch.nn.functional as Fn
+        with torch.no_grad():
+            xt = Fn.pad(torch.from_numpy(np.ascontiguousarray(x, dtype=F32)).permute(0, 3, 1, 2), (pl, pr, pt, pb))
+            wt = torch.from_numpy(np.ascontiguousarray(w, dtype=F32)).permute(3, 2, 0, 1).contiguous()
+            y = Fn.conv2d(xt, wt, stride=stride)
+            return np.ascontiguousarray(y.permute(0, 2, 3, 1).numpy())
     xp = np.zeros((B, H + pt + pb, W + pl + pr, Cin), dtype=acc)
     xp[:, pt:pt + H, pl:pl + W, :] = x
     wm = w.astype(acc)

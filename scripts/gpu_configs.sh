@@ -1,7 +1,7 @@
 #!/bin/bash
 # BASELINE.json configs on one GPU (bench lines only; parity for these shapes is in tests/test_gpu_parity.py)
 OUT=gpurun_out/${1:-cfg}; mkdir -p $OUT
-run() { tag=$1; shift; timeout 400 python bench.py --gpus 1 --cpu-images 0 "$@" 2>$OUT/$tag.err | tail -1 > $OUT/$tag.json; python - <<PY
+run() { tag=$1; shift; timeout 400 python bench.py --gpus 1 --cpu-seconds 0 --no-host-path "$@" 2>$OUT/$tag.err | tail -1 > $OUT/$tag.json; python - <<PY
 import json
 try:
     d=json.loads(open('$OUT/$tag.json').read())

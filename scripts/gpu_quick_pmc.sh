@@ -4,7 +4,7 @@ TAG=${1:-qp}; K=${2:-wino}
 bash scripts/gpu_quick.sh $TAG "$K"
 R=$(pwd); OUT=gpurun_out/$TAG; export TMPDIR=/tmp; cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o hp3d -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --cpu-images 0 > /dev/null 2> $R/$OUT/pmc_${C}_stderr.txt
+  timeout 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/$OUT/pmc_$C -o hp3d -- python $R/bench.py --gpus 1 --steps 2 --warmup 1 --cpu-seconds 0 --no-host-path > /dev/null 2> $R/$OUT/pmc_${C}_stderr.txt
   echo "pmc $C exit $?"
 done
 cd $R

@@ -14,6 +14,15 @@ import sys
 from collections import defaultdict
 
 
+def _tree_id():
+    try:
+        import subprocess
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        return subprocess.check_output(['git', 'rev-parse', '--short', 'HEAD'], cwd=root, text=True, stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        return 'unknown'
+
+
 def family(name):
     if 'conv_wino_kernel' in name:
         return 'conv_wino'
@@ -67,7 +76,7 @@ def main():
         except Exception:
             pass
     lines = ['# rocprofv3 summary %s' % tag, '',
-             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-images 0`',
+             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path`',
              '(PMC: separate `--kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, `--steps 2 --warmup 1`)', '',
              '| kernel family | launches | total ms | avg launch us | % GPU time | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch |',
              '|---|---|---|---|---|---|---|']
@@ -90,6 +99,7 @@ def main():
                 lines.append('%s HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (kf, rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
                 json.dump({"kernel": kf, "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
                            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
+                           "stamp": "profile tag %s, summarised %s, tree %s" % (tag, __import__('datetime').date.today().isoformat(), _tree_id()),
                            "workload": bench.get('config', {}).get('workload')},
                           open(os.path.join(dst, kf + '_traffic.json'), 'w'), indent=1)
     open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(lines) + '\n')

@@ -115,6 +115,14 @@ def test_full_pipeline_on_interpreter(emu_engine, synth_weights):
     ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
     for a, b in zip(out, ref):
         assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
+    # keypoints detected on the device == the reference's host functions on the returned maps
+    from hand3d_amd.utils import general as PG
+    c3d, kp_hw, kp_crop, scale, center = net.inference_keypoints(img, hs, True)
+    assert np.array_equal(c3d, out[5]) and np.array_equal(scale, out[2]) and np.array_equal(center, out[3])
+    assert np.array_equal(kp_crop[0], PG.detect_keypoints(out[4][0]))
+    assert np.array_equal(kp_hw[0], PG.trafo_coords(PG.detect_keypoints(out[4][0]), out[3], out[2], 256))
+    kp_hw2, kp_crop2, scale2, center2 = net.inference2d_keypoints(img)
+    assert np.array_equal(kp_hw2, kp_hw) and np.array_equal(kp_crop2, kp_crop)
 
 
 def test_local_variant_bone_rel_trafo_inv(emu_engine, synth_weights):
@@ -179,10 +187,14 @@ def test_winograd_kernel_on_interpreter(emu_engine, case):
         r = T.max_pool_2x2(r)
     emu_engine.set_option('conv_impl', 'winograd')
     try:
+        emu_engine.set_option('wino_splitk', '0')
         y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        emu_engine.set_option('wino_splitk', '1')       # small shapes under-fill the chip: channel steps split (not with a pool)
+        ys = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
     finally:
         emu_engine.set_option('conv_impl', 'mfma')
-    assert np.abs(y - r).max() < 1e-5
+        emu_engine.set_option('wino_splitk', '1')
+    assert np.abs(y - r).max() < 1e-5 and np.abs(ys - r).max() < 1e-5
 
 
 @pytest.mark.parametrize("case", [(1, 12, 14, 32, 128, 0), (2, 9, 11, 40, 64, 1)], ids=lambda c: "B%d_%dx%d_%d-%d_a%d" % c)
@@ -199,7 +211,53 @@ def test_winograd_7x7_as_3x3_blocks_on_interpreter(emu_engine, case):
         r = T.leaky_relu(r)
     emu_engine.set_option('conv_impl', 'winograd')
     try:
+        emu_engine.set_option('wino_splitk', '0')
         y = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+        emu_engine.set_option('wino_splitk', '1')       # 9 x Cin/32 (or /16) steps split over up to 16 workgroups
+        ys = emu_engine.conv2d(x, w, b, 1, bool(act), False)
     finally:
         emu_engine.set_option('conv_impl', 'mfma')
-    assert np.abs(y - r).max() < 1e-5
+        emu_engine.set_option('wino_splitk', '1')
+    assert np.abs(y - r).max() < 1e-5 and np.abs(ys - r).max() < 1e-5
+    assert not np.array_equal(y, ys), "the split-K variant did not run (different summation order expected)"
+
+
+def _near_tie_scoremaps(trial, rng):
+    """[2,32,32,21] score maps whose peak has a neighbour 1 ulp below it (an EARLIER interpolated position of the x8
+    up-sampled map can then round up to the peak value) or an exact earlier tie."""
+    sm = rng.standard_normal((2, 32, 32, 21)).astype(np.float32)
+    if trial == 0:
+        return sm
+    for b in range(2):
+        for c in range(21):
+            i, j = int(rng.integers(1, 31)), int(rng.integers(1, 31))
+            peak = np.float32(3.0 + c)
+            sm[b, i, j, c] = peak
+            below = np.nextafter(peak, np.float32(0))
+            if trial == 1:
+                sm[b, i, j - 1, c] = below
+            elif trial == 2:
+                sm[b, i - 1, j, c] = below
+            else:
+                sm[b, i - 1, j - 1, c] = peak
+    return sm
+
+
+def test_device_detect_keypoints_equals_reference_on_upsampled_map(emu_engine):
+    """hp3d_detect_keypoints == detect_keypoints(resize_images(map, (256,256))) (utils/general.py:331-344 after
+    CHP3D.py:97) without the large map -- including the cases where 8 x argmax(small map) is NOT the answer."""
+    from hand3d_amd.utils import general as PG
+    rng = np.random.default_rng(0)
+    shortcut_wrong = 0
+    for trial in range(4):
+        sm = _near_tie_scoremaps(trial, rng)
+        up = T.resize_bilinear_legacy(sm, 256, 256)
+        ref = np.stack([PG.detect_keypoints(up[b]) for b in range(2)])
+        got = emu_engine.detect_keypoints(sm)
+        assert got.dtype == np.int32 and np.array_equal(ref, got), trial
+        shortcut_wrong += int((np.stack([PG.detect_keypoints(sm[b]) for b in range(2)]) * 8 != ref).any(axis=2).sum())
+    assert shortcut_wrong > 0, "the engineered cases no longer exercise the rounding hazard"
+    # a non-square, non-x8 geometry
+    sm = rng.standard_normal((1, 30, 40, 5)).astype(np.float32)
+    up = T.resize_bilinear_legacy(sm, 100, 90)
+    assert np.array_equal(emu_engine.detect_keypoints(sm, (100, 90))[0], PG.detect_keypoints(up[0]))

@@ -629,10 +629,17 @@ def test_hipgraph_replay_matches_plain_launches(net, synth_weights):
 
     try:
         plain = run()
+        c0, r0 = eng.counter('graph_captures'), eng.counter('graph_replays')
         eng.set_option('graph', '1')
-        for g in [run() for _ in range(4)]:                  # warm-up, capture, replay, replay
+        for g in [run() for _ in range(4)]:                  # warm-up, capture (+ launch), replay, replay
             for a, b in zip(g, plain):
                 assert np.array_equal(a, b)
+        assert eng.counter('graph_captures') == c0 + 1 and eng.counter('graph_replays') == r0 + 3, \
+            "the hipGraph path did not run (capture failed silently?)"
+        eng.set_profiling(1)                                  # per-launch events need plain launches: no replay
+        run()
+        eng.set_profiling(0)
+        assert eng.counter('graph_replays') == r0 + 3
         crop.upload(synth.make_batch(9200, 2, 256, 256))      # same pointers, new data
         eng.set_option('graph', '0')
         plain2 = run()
@@ -671,3 +678,30 @@ def test_conv7x7_on_winograd_kernel_vs_oracle(gpu_engine, case):
     finally:
         gpu_engine.set_option('conv_impl', 'mfma')
     assert np.abs(y - r).max() < 5e-5
+
+
+def test_device_keypoints_equal_reference_host_functions(net, synth_weights):
+    """hp3d_infer_full_kp / hp3d_infer_2d_kp / hp3d_detect_keypoints: detect_keypoints + trafo_coords
+    (utils/general.py:331-357) on the device, bit-exact with the host functions applied to the returned 256x256 maps --
+    ties and the up-sampling rounding hazard included (tests/test_emu_kernels.py::_near_tie_scoremaps)."""
+    from hand3d_amd.utils import general as PG
+    from test_emu_kernels import _near_tie_scoremaps
+    img = synth.make_batch(700, 3, 240, 320)
+    hs = synth.hand_sides(3)
+    full = net.inference(img, hs, True)
+    c3d, kp_hw, kp_crop, scale, center = net.inference_keypoints(img, hs, True)
+    assert np.array_equal(c3d, full[5]) and np.array_equal(scale, full[2]) and np.array_equal(center, full[3])
+    assert kp_hw.dtype == np.float64 and kp_crop.dtype == np.float64
+    for i in range(3):
+        kp = PG.detect_keypoints(full[4][i])
+        assert np.array_equal(kp_crop[i], kp)
+        assert np.array_equal(kp_hw[i], PG.trafo_coords(kp, full[3][i:i + 1], full[2][i:i + 1], 256))
+    kp_hw2, kp_crop2, scale2, center2 = net.inference2d_keypoints(img)
+    assert np.array_equal(kp_hw2, kp_hw) and np.array_equal(kp_crop2, kp_crop) and np.array_equal(scale2, scale)
+    rng = np.random.default_rng(0)
+    for trial in range(4):
+        sm = _near_tie_scoremaps(trial, rng)
+        up = net.engine.resize_bilinear(sm, 256, 256)
+        ref = np.stack([PG.detect_keypoints(up[b]) for b in range(2)])
+        assert np.array_equal(net.engine.detect_keypoints(sm), ref), trial
+        assert np.array_equal(net.engine.argmax2d(up).astype(np.float64), ref), trial

@@ -58,6 +58,9 @@ def test_reference_fixtures_full_pipeline_c1(net, gold):
         kp = detect_keypoints(np.squeeze(o['kpmap']))
         assert np.array_equal(kp, g[k + 'kp_crop'])
         assert np.array_equal(trafo_coords(kp, o['center'], o['scale'], 256), g[k + 'kp_uv'])
+        # the same two host steps evaluated on the device (hp3d_infer_full_kp)
+        od = net.engine.infer_full(img, hs, outputs=('kp_crop', 'kp_hw'))
+        assert np.array_equal(od['kp_crop'][0], g[k + 'kp_crop']) and np.array_equal(od['kp_hw'][0], g[k + 'kp_uv'])
         ev.feed(g[k + 'keypoint_coord3d'][0], np.ones(21), o['coord3d'][0])
     mean_epe = ev.get_measures(0.0, 0.05, 20)[0]
     print("mean EPE engine vs reference-code fixtures: %.3e" % mean_epe)

@@ -66,6 +66,23 @@ def test_corruption_is_detected(tmp_path):
         C.read_bundle(prefix)
 
 
+def test_discarded_entries_are_never_decoded(tmp_path):
+    """load_weights_from_snapshot touches only the tensors it keeps (utils/general.py:619-646): a damaged optimiser slot
+    in the discard list must not stop the load."""
+    t = {'PoseNet2D/conv1_1/weights': np.arange(24, dtype=np.float32).reshape(2, 3, 4),
+         'PoseNet2D/conv1_1/weights/Adam': np.ones((2, 3, 4), np.float32)}
+    prefix = C.write_bundle(str(tmp_path / 'm'), t)
+    raw = bytearray(open(prefix + '.data-00000-of-00001', 'rb').read())
+    pos = bytes(raw).find(np.ones(24, np.float32).tobytes())
+    assert pos >= 0
+    raw[pos + 7] ^= 0x10                                              # corrupt the Adam slot only
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(raw))
+    with pytest.raises(ValueError):
+        C.read_bundle(prefix)
+    w = C.load_weights_from_snapshot(prefix, discard_list=['Adam', 'global_step', 'beta'])
+    assert list(w) == ['PoseNet2D/conv1_1/weights'] and np.array_equal(w['PoseNet2D/conv1_1/weights'], t['PoseNet2D/conv1_1/weights'])
+
+
 def test_snapshot_feeds_the_engine_loader(tmp_path, emu_engine, synth_weights):
     """A retrained snapshot (with optimizer slots) goes through the converter into init_from_dict."""
     from hand3d_amd import ColorHandPose3DNetwork

@@ -9,11 +9,14 @@
 //   * the im2col row of a pixel is never materialised: lane (pixel, k-half) gathers its 14 operands straight from the
 //     image with buffer loads (zero padding and the K tail = out-of-range offsets); the next tile's 14 loads fly under
 //     the current tile's MFMAs and stores;
-//   * the MFMA is issued as D[cout][pixel] = W^T X (weights as the row operand): the four accumulator registers 4a..4a+3
-//     of a lane are then four CONSECUTIVE couts of ONE pixel -> 8 stores of 16 B per lane and 32 x 64 block instead of
-//     32 stores of 4 B (the layer is bound by its 13 MB / image of stores; 4-byte stores were issue-bound at 0.44 of HBM);
 //   * the bias rides in the spare K row (k = 27: weight row = bias, image operand = 1.0), so the epilogue is only the
 //     leaky-ReLU and the stores;
+//   * stores (the layer is bound by its 13 MB / image of output): D[pixel][cout], one 4-byte store per accumulator
+//     register -- 32 lanes cover the 32 couts (128 contiguous bytes) of one pixel.  Measured alternatives
+//     (profiles/r02_tuning_notes.md): 16-byte stores straight from a D[cout][pixel] register layout (32 bytes per pixel
+//     and instruction) are 30 % SLOWER; the same block transposed through LDS into 16-byte full-row stores runs at exactly
+//     the same speed as this form -- the store form is not the limiter.  A pure fill kernel reaches 5.1-5.8 TB/s on this
+//     GPU (scripts/micro/write_bw.hip); this kernel writes at 3.6 TB/s next to its gathers and 28 MFMAs per tile;
 //   * no LDS, ~100 registers: four waves per SIMD hide the rest; a workgroup walks a strip of tiles.
 #include "hp3d_common.h"
 
@@ -50,7 +53,7 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
     const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)p.out_cs * 4u);
     constexpr int OOR = (int)0x80000000;
 
-    // A operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
+    // image operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
     const int y = ty * FT_TH + 2 * wave + (m >> 4);
     auto gather = [&](int tx, float (&a)[FK]) {
         const int x = tx * FT_TW + (m & 15);
@@ -69,33 +72,26 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
     for (int tx = tx0; tx < tx1; ++tx) {
         if (tx + 1 < tx1) gather(tx + 1, a_nxt);
         f32x16 acc0, acc1;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         {
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc0 = HP3D_MFMA_32x32x2(bw[0][0], a_cur[0], zero);
-            acc1 = HP3D_MFMA_32x32x2(bw[1][0], a_cur[0], zero);
-        }
+            acc0 = HP3D_MFMA_32x32x2(a_cur[0], bw[0][0], zero);
+            acc1 = HP3D_MFMA_32x32x2(a_cur[0], bw[1][0], zero);
 #pragma unroll
-        for (int kk = 1; kk < FK; ++kk) {
-            acc0 = HP3D_MFMA_32x32x2(bw[0][kk], a_cur[kk], acc0);
-            acc1 = HP3D_MFMA_32x32x2(bw[1][kk], a_cur[kk], acc1);
-        }
-        // D[cout][pixel]: this lane holds pixel m of the wave's 2 x 16 row block; accumulator register 4a + j of half nb
-        // is cout 32 nb + 8 a + 4 kh + j -> one 16-byte store per (a, nb)
-        const int oy = ty * FT_TH + 2 * wave + (m >> 4), ox = tx * FT_TW + (m & 15);
-        const int base = (oy < p.H && ox < p.W) ? (((b * p.H + oy) * p.W + ox) * p.out_cs + 4 * kh) * 4 : OOR;
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            f32x4 v0 = {acc0[4 * a], acc0[4 * a + 1], acc0[4 * a + 2], acc0[4 * a + 3]};
-            f32x4 v1 = {acc1[4 * a], acc1[4 * a + 1], acc1[4 * a + 2], acc1[4 * a + 3]};
-            if (p.act) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v0[j] = fmaxf(v0[j], HP3D_LEAKY_SLOPE * v0[j]);
-                    v1[j] = fmaxf(v1[j], HP3D_LEAKY_SLOPE * v1[j]);
-                }
+            for (int kk = 1; kk < FK; ++kk) {
+                acc0 = HP3D_MFMA_32x32x2(a_cur[kk], bw[0][kk], acc0);
+                acc1 = HP3D_MFMA_32x32x2(a_cur[kk], bw[1][kk], acc1);
             }
-            HP3D_BUFFER_STORE16(orsrc, v0, base, a * 32);
-            HP3D_BUFFER_STORE16(orsrc, v1, base, 128 + a * 32);
+            // accumulator register r <-> pixel (r & 3) + 8 (r >> 2) + 4 kh of the row block, column = cout m of the half
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pm = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int oy = ty * FT_TH + 2 * wave + (pm >> 4), ox = tx * FT_TW + (pm & 15);
+                const int base = (oy < p.H && ox < p.W) ? (((b * p.H + oy) * p.W + ox) * p.out_cs + m) * 4 : OOR;
+                float v0 = acc0[r], v1 = acc1[r];
+                if (p.act) { v0 = fmaxf(v0, HP3D_LEAKY_SLOPE * v0); v1 = fmaxf(v1, HP3D_LEAKY_SLOPE * v1); }
+                HP3D_BUFFER_STORE4(orsrc, v0, base, 0);
+                HP3D_BUFFER_STORE4(orsrc, v1, base, 128);
+            }
         }
 #pragma unroll
         for (int kk = 0; kk < FK; ++kk) a_cur[kk] = a_nxt[kk];

@@ -221,15 +221,18 @@ void conv_wino_kernel(const ConvParams p) {
         cy_ = r / tile_blocks;
         tb_ = r - cy_ * tile_blocks;
     };
-    auto first_step_of = [&](int kz) { return SPLITK ? (kz * nsteps) / p.ksplit : 0; };
+    // (every quantity here is wave-uniform; say so, or hipcc wraps the buffer loads that take them as scalar offsets into
+    //  waterfall loops)
+    auto first_step_of = [&](int kz) { return SPLITK ? HP3D_READFIRSTLANE((kz * nsteps) / p.ksplit) : 0; };
     int item = blockIdx.x;
     int kz, cy, tblock;
     split_of(item, kz, cy, tblock);
     int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
-    loader_setup(tblock, true, s0 / csteps);
+    const int sub0 = SPLITK ? HP3D_READFIRSTLANE(s0 / csteps) : 0;
+    loader_setup(tblock, true, sub0);
     table_write(tblock, 0, kz);
     int wvoff = (cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
-    window_fetch((s0 % csteps) * (WCK * 4));
+    window_fetch((s0 - sub0 * csteps) * (WCK * 4));
     b_fetch(0, wvoff, soff_of(0, s0));
     b_fetch(1, wvoff, soff_of(1, s0));
     b_fetch(2, wvoff, soff_of(2, s0));
@@ -254,7 +257,7 @@ void conv_wino_kernel(const ConvParams p) {
             // windows go next, and B(p+4) is issued behind plane p's MFMAs -- the windows (the next step's, or the
             // next item's first) then have 4 planes (~1.8 us) to arrive before anything depends on them.
             const int nvoff = lasts ? n_wvoff : wvoff;
-            const int nstep = lasts ? n_s0 : step + 1;
+            const int nstep = lasts ? (SPLITK ? n_s0 : 0) : step + 1;
             ab0 = cur * (VBUF_FLOATS * 4) + va_lane0;
             ab1 = NT == 32 ? ab0 + 14 * PLANE_FLOATS * 4 : cur * (VBUF_FLOATS * 4) + va_lane1;
             HP3D_OPAQUE_V(ab0);
@@ -262,7 +265,7 @@ void conv_wino_kernel(const ConvParams p) {
             a_fetch(0, 0);                       // first: plane 0's MFMAs wait for exactly this
             b_fetch(3, wvoff, soff_of(3, step));
             // (virtual) channels of the next step: sub-kernel nsub_ = (step + 1) / csteps, channel step ncs
-            const int nsub_ = NSUB == 1 ? 0 : nstep / csteps;
+            const int nsub_ = NSUB == 1 ? 0 : SPLITK ? HP3D_READFIRSTLANE(nstep / csteps) : lasts ? 0 : (step + 1) / csteps;
             const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;      // (NSUB == 1: nsteps == csteps)
             if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
@@ -280,7 +283,7 @@ void conv_wino_kernel(const ConvParams p) {
                 for (int gj = 1; gj < 4 * G; ++gj)
                     M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
                 if (pl == 0) {               // the window loads are issued between plane 0's MFMAs, not in front of them
-                    window_fetch(ncs * (WCK * 4));
+                    window_fetch(NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (WCK * 4)) : ncs * (WCK * 4));   // (uniform; hipcc cannot always tell)
                     HP3D_SCHED_GROUP(HP3D_SG_DS_READ, G);
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
@@ -303,6 +306,7 @@ void conv_wino_kernel(const ConvParams p) {
         {   // the next item (its tile table is written here, hidden under this item's MFMAs)
             const bool has_next = n_item < nitems;
             if (has_next) split_of(n_item, n_kz, n_cy, n_tblock);
+            if (SPLITK) { n_kz = HP3D_READFIRSTLANE(n_kz); n_cy = HP3D_READFIRSTLANE(n_cy); n_tblock = HP3D_READFIRSTLANE(n_tblock); }
             n_s0 = first_step_of(n_kz);
             table_write(n_tblock, (k + 1) & 1, n_kz);
             n_wvoff = (n_cy * (COUTS / 32) + wcout) * 4096 + lane * 16;

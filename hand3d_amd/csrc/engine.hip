@@ -244,6 +244,10 @@ struct hp3d_ctx {
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
     int use_first = 1;         // conv1_1 on its own kernel (conv_first.hip); conv_impl=direct keeps it on the general one
+    int nstreams = -1;         // whole-path calls: halves of the batch on two HIP streams (option "streams"; -1 auto)
+    hp3d_ctx* kid = nullptr;   // the second stream's context: own stream + arena, SHARES this context's weight blob
+    bool shared_weights = false;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
@@ -748,7 +752,7 @@ int run_kp_detect(hp3d_ctx* ctx, int B, int32_t* kp_crop, double* kp_image, bool
 int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                     float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
                     float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
-                    int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
+                    int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr, bool no_sync = false) {
     if (!ctx) return HP3D_ERR_ARG;
     if ((!image && !image_u8) || !hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
     CHK(check_img(ctx, B, H, W));
@@ -786,7 +790,7 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
     if (!dev) CHK(copy_out(ctx, kp_scoremap, ctx->d_kpmap, (size_t)B * 256 * 256 * 21, false));
     CHK(copy_out(ctx, coord3d, ctx->d_coord, (size_t)B * 63, dev));
     CHK(copy_out(ctx, hand_mask, ctx->d_mask, (size_t)B * H * W, dev));
-    if (!dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!dev && !no_sync) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
@@ -808,15 +812,15 @@ int auto_micro_batch(const hp3d_ctx* ctx, int B, int H, int W) {
     return (B + chunks - 1) / chunks;
 }
 
-int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+int infer_full_chunked1(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
                        float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
                        float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
-                       int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
+                       int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr, bool no_sync = false) {
     if (!ctx) return HP3D_ERR_ARG;
     const int mb = auto_micro_batch(ctx, B, H, W);
     if (mb <= 0 || B <= mb)
         return infer_full_impl(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center, kp_scoremap,
-                               coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image);
+                               coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image, no_sync);
     CHK(check_img(ctx, B, H, W));
     if (!hand_side) HP3D_FAIL(ctx, HP3D_ERR_ARG, "image / hand_side is NULL");
     const int saved_prof = ctx->profiling;
@@ -829,10 +833,80 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
                              off(hand_scoremap, (size_t)H * W * 2), off(image_crop, 256 * 256 * 3), off(scale_crop, 1),
                              off(center, 2), off(kp_scoremap, 256 * 256 * 21), off(coord3d, 63), off(hand_mask, (size_t)H * W),
                              dev, image_u8 ? image_u8 + (size_t)b0 * Hin * Win * 3 : nullptr, Hin, Win,
-                             kp_crop ? kp_crop + (size_t)b0 * 42 : nullptr, kp_image ? kp_image + (size_t)b0 * 42 : nullptr);
+                             kp_crop ? kp_crop + (size_t)b0 * 42 : nullptr, kp_image ? kp_image + (size_t)b0 * 42 : nullptr, no_sync);
     }
     ctx->profiling = saved_prof;
     return rc;
+}
+
+// Two HIP streams per GPU: the batch is cut in two halves that run the whole path concurrently, each on its own stream and
+// arena (the second one owned by a child context that shares the weight blob).  Every image is independent, and the
+// persistent Winograd kernels leave CUs idle in their last round of work items (1600 items on 256 CUs = 6.25 rounds) and
+// between dependent launches: the other half's kernels fill exactly those holes.  Measured (profiles/r02_tuning_notes.md):
+// float32 B=32 320x320 1558 -> 1615 img/s, 240x320 +1.8 %, 480x640 +6.9 %, B=16 +4.5 %, B=64 +6.4 %, f16 trunks +2.1 %; four
+// streams of 8 images lose 8 % (too few items per launch) -- hence "auto" = 2 streams from 16 images per call, 1 below.
+// Per-launch profiling and hipGraph replay keep one stream.  A half-batch may take another kernel plan than the whole
+// batch would (small-batch Winograd split-K): results equal the one-stream run to rounding, discrete decisions included.
+int kid_sync_state(hp3d_ctx* ctx) {
+#ifdef HP3D_EMU
+    return -1;
+#else
+    if (!ctx->kid) {
+        hp3d_ctx* k = new hp3d_ctx();
+        k->device = ctx->device;
+        if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            delete k;
+            return -1;
+        }
+        k->shared_weights = true;
+        ctx->kid = k;
+    }
+    hp3d_ctx* k = ctx->kid;
+    k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
+    k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
+    k->use_first = ctx->use_first; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
+    return 0;
+#endif
+}
+
+int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, const float* hand_side,
+                       float* hand_scoremap, float* image_crop, float* scale_crop, float* center, float* kp_scoremap,
+                       float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
+                       int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
+    if (!ctx) return HP3D_ERR_ARG;
+    const int ns = ctx->nstreams >= 0 ? ctx->nstreams : (B >= 16 ? 2 : 1);
+    if (ns < 2 || B < 2 || ctx->profiling || ctx->use_graph || ctx->conv_naive || ctx->shared_weights || !hand_side ||
+        (!image && !image_u8) || kid_sync_state(ctx) != 0)
+        return infer_full_chunked1(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center, kp_scoremap,
+                                   coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image);
+#ifndef HP3D_EMU
+    hp3d_ctx* k = ctx->kid;
+    const int b0 = (B + 1) / 2, b1 = B - b0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    // the child's stream starts after everything already queued on the parent's (inputs produced there) ...
+    HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(k->stream, ctx->ev_fork, 0));
+    auto off = [&](float* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
+    int rc = infer_full_chunked1(k, b1, H, W, image ? image + (size_t)b0 * H * W * 3 : nullptr, hand_side + (size_t)b0 * 2,
+                                 off(hand_scoremap, (size_t)H * W * 2), off(image_crop, 256 * 256 * 3), off(scale_crop, 1),
+                                 off(center, 2), off(kp_scoremap, 256 * 256 * 21), off(coord3d, 63), off(hand_mask, (size_t)H * W),
+                                 dev, image_u8 ? image_u8 + (size_t)b0 * Hin * Win * 3 : nullptr, Hin, Win,
+                                 kp_crop ? kp_crop + (size_t)b0 * 42 : nullptr, kp_image ? kp_image + (size_t)b0 * 42 : nullptr, true);
+    if (rc != 0) { set_error(ctx, k->err.c_str()); }
+    const int rc0 = rc != 0 ? rc : infer_full_chunked1(ctx, b0, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
+                                                       kp_scoremap, coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image, true);
+    // ... and the parent's stream continues only after the child's half is done
+    HIPCHK(ctx, hipEventRecord(ctx->ev_join, k->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (!dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return rc0;
+#else
+    return HP3D_ERR_UNSUPPORTED;
+#endif
 }
 
 int posenet_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image_crop, float* s0, float* s1, float* s2, bool dev) {
@@ -983,6 +1057,12 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     if (!ctx) return HP3D_ERR_ARG;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->kid) { hp3d_destroy(ctx->kid); ctx->kid = nullptr; }
+#ifndef HP3D_EMU
+    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+#endif
+    if (ctx->shared_weights) { ctx->blob = nullptr; ctx->blob16 = nullptr; }     // owned by the parent context
     float** fp[] = {&ctx->blob, &ctx->bufA, &ctx->bufB, &ctx->col, &ctx->d_image, &ctx->d_hs, &ctx->d_large,
                     &ctx->d_crop, &ctx->d_center, &ctx->d_scale, &ctx->d_cropsize, &ctx->d_kpmap, &ctx->d_coord,
                     &ctx->d_mask, &ctx->d_segsmall, &ctx->d_concat, &ctx->d_sm[0], &ctx->d_sm[1], &ctx->d_sm[2],
@@ -1097,6 +1177,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {
         ctx->conv_naive = (v == "naive");
         ctx->use_wino = (v == "direct" || v == "naive") ? 0 : (v == "winograd") ? 2 : 1;   // mfma = auto

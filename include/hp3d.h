@@ -61,6 +61,11 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            fills the chip, >= 256 work items) | "direct" (never Winograd: bit-identical to an fmaf
  *                            chain) | "winograd" (whenever the shape allows; per-op hp3d_conv2d then refuses other
  *                            shapes) | "naive" (debug cross-check kernel, never a fallback);
+ *          "streams"      = "auto" (default) | "1" | "2": whole-path calls run the two halves of their batch concurrently
+ *                            on two HIP streams (second arena, shared weights; fills the tail rounds of the persistent
+ *                            kernels and the launch gaps).  auto = 2 from 16 images per call.  Results equal "1" to
+ *                            rounding (images are independent; a half may take the small-batch kernel plan);
+ *                            profiling / graph replay use one stream;
  *          "wino_splitk"  = "1" (default) | "0": Winograd layers whose work items under-fill the chip (small batches) split
  *                            their channel steps over up to 16 workgroups and sum float32 partials in a fixed order;
  *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N

@@ -16,3 +16,5 @@ run c1_b1_240x320 --batch 1 --height 240 --width 320 --steps 50 --warmup 10
 run c5_f16_b128_480x640 --dtype f16 --batch 128 --height 480 --width 640 --steps 3 --warmup 1
 run f32_b32_480x640 --batch 32 --height 480 --width 640 --steps 3 --warmup 1
 run f16_b32_320 --dtype f16 --batch 32 --steps 10 --warmup 3
+run c4_b32_240x320 --batch 32 --height 240 --width 320 --steps 10 --warmup 3
+run f32_b8_240x320 --batch 8 --height 240 --width 320 --steps 20 --warmup 5

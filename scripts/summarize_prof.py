@@ -31,7 +31,7 @@ def family(name):
     if 'conv_first_kernel' in name:
         return 'conv_first'
     for k in ('conv_splitk_reduce', 'preprocess_u8', 'bone_rel_inv', 'fc_partial', 'fc_reduce', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
-              'copy_channels', 'concat_handside', 'lift_epilogue', 'avgpool8', 'pad_channels'):
+              'kp_detect', 'copy_channels', 'concat_handside', 'lift_epilogue', 'avgpool8', 'pad_channels'):
         if k in name:
             return k
     return 'other:' + name[:40]
@@ -76,7 +76,9 @@ def main():
         except Exception:
             pass
     lines = ['# rocprofv3 summary %s' % tag, '',
-             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path`',
+             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path --option streams=1`',
+             '(one HIP stream, so that kernel durations are not inflated by the overlap the default two-stream mode is there to create;',
+             ' the bench line below is the DEFAULT command, whose roofline block comes from its own serial, event-timed pass)',
              '(PMC: separate `--kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, `--steps 2 --warmup 1`)', '',
              '| kernel family | launches | total ms | avg launch us | % GPU time | HBM read MB/launch (2x FETCH_SIZE) | HBM write MB/launch |',
              '|---|---|---|---|---|---|---|']

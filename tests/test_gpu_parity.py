@@ -705,3 +705,45 @@ def test_device_keypoints_equal_reference_host_functions(net, synth_weights):
         ref = np.stack([PG.detect_keypoints(up[b]) for b in range(2)])
         assert np.array_equal(net.engine.detect_keypoints(sm), ref), trial
         assert np.array_equal(net.engine.argmax2d(up).astype(np.float64), ref), trial
+
+
+def test_two_streams_equal_one_stream(net, synth_weights):
+    """hp3d_set_option("streams", "2"): the two halves of a batch on two HIP streams (second arena, shared weights) give
+    the single-stream results -- identical discrete decisions (mask, centre, scale, arg-max keypoints), floats equal to
+    rounding (a half-batch may take the small-batch kernel plan: other summation order) -- for host- and device-pointer
+    calls, odd batch sizes included."""
+    def same(a, b, k):
+        if a is None and b is None:
+            return
+        if k in ('mask', 'center', 'scale', 'kp_crop', 'kp_hw'):
+            assert np.array_equal(a, b), k
+        else:
+            assert np.abs(a - b).max() < 2e-5, (k, float(np.abs(a - b).max()))
+    eng = net.engine
+    img = synth.make_batch(8100, 5, 240, 320)
+    hs = synth.hand_sides(5)
+    outs = ('scoremap', 'crop', 'scale', 'center', 'kpmap', 'coord3d', 'kp_crop', 'kp_hw')
+    try:
+        eng.set_option('streams', '1')
+        one = eng.infer_full(img, hs, want_mask=True, outputs=outs)
+        eng.set_option('streams', '2')
+        two = eng.infer_full(img, hs, want_mask=True, outputs=outs)
+        for k in one:
+            same(one[k], two[k], k)
+        u8 = np.clip(np.rint((synth.make_batch(8200, 3, 320, 320) + 0.5) * 255.0), 0, 255).astype(np.uint8)
+        a = eng.infer_full_u8(u8, hs[:3])
+        eng.set_option('streams', '1')
+        b = eng.infer_full_u8(u8, hs[:3])
+        for k in a:
+            same(a[k], b[k], k)
+        # device-pointer entry point: the child's stream must see inputs written on the parent's stream and vice versa
+        eng.set_option('streams', '2')
+        d_img, d_hs, d_c = eng.to_device(img), eng.to_device(hs), eng.dev_alloc(5 * 63 * 4)
+        for _ in range(3):
+            eng.infer_full_dev(5, 240, 320, int(d_img), int(d_hs), coord3d=int(d_c))
+        eng.sync()
+        assert np.array_equal(eng.to_host(d_c, (5, 21, 3)), two['coord3d'])
+        for buf in (d_img, d_hs, d_c):
+            buf.free()
+    finally:
+        eng.set_option('streams', 'auto')

@@ -126,7 +126,7 @@ def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s):
     return cpu, par
 
 
-def traffic_record(dom, workload_str):
+def traffic_record(dom, workload_str, dtype):
     """HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of THIS command (counters cannot be read
     in-process): scripts/gpu_round.sh <tag> pmc -> scripts/summarize_prof.py -> profiles/<family>_traffic.json.  The number
     is quoted only for the workload string it was measured on, together with the stamp the summariser wrote into the file
@@ -134,7 +134,7 @@ def traffic_record(dom, workload_str):
     tpath = os.path.join(ROOT, 'profiles', '%s_traffic.json' % dom)
     try:
         t = json.load(open(tpath))
-        if t.get('workload') != workload_str:
+        if t.get('workload') != workload_str or t.get('dtype', 'f32') != dtype:
             return None, None
         return round(t['hbm_bytes_per_launch']), {"file": os.path.relpath(tpath, ROOT), "stamp": t.get('stamp', t.get('source')),
                                                   "method": "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate "
@@ -251,9 +251,9 @@ def main():
         if dom == 'conv_wino':
             roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
                             "blocks: 144/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
-        workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 %s in HBM, %d images/GPU/step" % (H, W, a.dtype, B)) \
-            if a.workload == 'full' else ("inference_pose2d, 256x256x3 %s in HBM, %d images/GPU/step" % (a.dtype, B))
-        roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str)
+        workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step" % (H, W, B)) \
+            if a.workload == 'full' else ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B)
+        roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str, a.dtype)
         roof["timing"] = "HIP events on the engine stream around each launch, separate pass of %d steps (%.3f ms/step profiled)" % (
             a.steps, dt_prof / a.steps * 1e3)
         others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0]) if k != dom and k.startswith('conv')]

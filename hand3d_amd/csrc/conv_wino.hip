@@ -31,6 +31,9 @@
 //     of 196 multiplies per 2x2 outputs, 45 steps per item.
 #include "hp3d_common.h"
 #include <cstdlib>
+#ifndef HP3D_WINO_ABL
+#define HP3D_WINO_ABL 0          // timing ablations (scripts/gpu_abl.sh); any non-zero value computes wrong results
+#endif
 #include <cstring>
 #include <type_traits>
 
@@ -143,8 +146,13 @@ void conv_wino_kernel(const ConvParams p) {
 
     f32x4 d[16];
     auto window_fetch = [&](int soff) {
+#if HP3D_WINO_ABL & 2
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { f32x4 t = {1.f + soff, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(t)); d[e] = t; }
+#else
 #pragma unroll
         for (int e = 0; e < 16; ++e) d[e] = HP3D_BUFFER_LOAD16(irsrc, wv[e], soff);
+#endif
     };
     auto transform_commit = [&](int buf) {
         // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -299,7 +307,9 @@ void conv_wino_kernel(const ConvParams p) {
                 if (pl == 12) transform_commit(cur ^ 1);      // its LDS writes land under planes 13..15
             }
             HP3D_SCHED_BARRIER();
+#if !(HP3D_WINO_ABL & 1)
             __syncthreads();             // V[cur^1] complete, V[cur] free
+#endif
             cur ^= 1;
         };
         step_body(s0, std::true_type{});

@@ -229,6 +229,8 @@ struct hp3d_ctx {
     double* d_kpimg = nullptr;   // [B,21,2] float64 (trafo_coords of the detected keypoints)
     int* d_kpcrop = nullptr;     // [B,21,2] int32 (detect_keypoints: row, col in the crop)
     void* comm = nullptr;        // ncclComm_t (hp3d_comm_init)
+    float* d_gather = nullptr;   // reusable send + receive staging of hp3d_allgather[_dev] (no allocation per step)
+    size_t gather_floats = 0;
     int comm_rank = 0, comm_size = 1;
     int* d_seed = nullptr;
     unsigned long long* d_keys = nullptr;
@@ -1071,6 +1073,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     for (float** p : fp)
         if (*p) hipFree(*p);
     if (ctx->d_kpimg) hipFree(ctx->d_kpimg);
+    if (ctx->d_gather) hipFree(ctx->d_gather);
 #ifndef HP3D_EMU
     if (ctx->upload_done) hipEventDestroy(ctx->upload_done);
     if (ctx->copy_stream) hipStreamDestroy(ctx->copy_stream);
@@ -1898,14 +1901,23 @@ int hp3d_bcast_weights(hp3d_ctx* ctx, int root) {
     ctx->prec = f16;
     return 0;
 }
+static int gather_staging(hp3d_ctx* ctx, size_t floats) {
+    if (floats > ctx->gather_floats) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        CHK(dev_realloc(ctx, &ctx->d_gather, floats));
+        ctx->gather_floats = floats;
+    }
+    return 0;
+}
 int hp3d_allgather(hp3d_ctx* ctx, const float* send_host, int count, float* recv_host) {
     if (!ctx || !ctx->comm || !send_host || !recv_host || count < 1) return HP3D_ERR_ARG;
     Rccl* R = rccl(ctx);
     if (!R) return HP3D_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    Scratch S(ctx);
-    float* d_send = S.upload(send_host, (size_t)count); NN(ctx, d_send);
-    float* d_recv = S.alloc<float>((size_t)count * ctx->comm_size); NN(ctx, d_recv);
+    CHK(gather_staging(ctx, (size_t)count * (ctx->comm_size + 1)));
+    float* d_send = ctx->d_gather;
+    float* d_recv = ctx->d_gather + count;
+    HIPCHK(ctx, hipMemcpyAsync(d_send, send_host, sizeof(float) * count, hipMemcpyHostToDevice, ctx->stream));
     NCCLCHK(ctx, R, R->AllGather(d_send, d_recv, (size_t)count, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(recv_host, d_recv, sizeof(float) * count * ctx->comm_size, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1916,8 +1928,8 @@ int hp3d_allgather_dev(hp3d_ctx* ctx, const float* send_dev, int count, float* r
     Rccl* R = rccl(ctx);
     if (!R) return HP3D_ERR_UNSUPPORTED;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    Scratch S(ctx);
-    float* d_recv = S.alloc<float>((size_t)count * ctx->comm_size); NN(ctx, d_recv);
+    CHK(gather_staging(ctx, (size_t)count * ctx->comm_size));
+    float* d_recv = ctx->d_gather;
     NCCLCHK(ctx, R, R->AllGather(send_dev, d_recv, (size_t)count, ncclFloat, (ncclComm_t)ctx->comm, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(recv_host, d_recv, sizeof(float) * count * ctx->comm_size, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

@@ -17,7 +17,12 @@
 //     and instruction) are 30 % SLOWER; the same block transposed through LDS into 16-byte full-row stores runs at exactly
 //     the same speed as this form -- the store form is not the limiter.  A pure fill kernel reaches 5.1-5.8 TB/s on this
 //     GPU (scripts/micro/write_bw.hip); this kernel writes at 3.6 TB/s next to its gathers and 28 MFMAs per tile;
-//   * no LDS, ~100 registers: four waves per SIMD hide the rest; a workgroup walks a strip of tiles.
+//   * no LDS, ~100 registers: four waves per SIMD hide the rest; a workgroup walks a strip of tiles;
+//   * F16 = true (half-precision trunks, BASELINE config 5): operands rounded to half (what the f16 MFMA of the general kernel
+//     multiplies), float32 accumulate, and the 32 x 64 block leaves as HALVES: 2-byte stores would be issue-bound, so the wave's
+//     block is transposed through a private 4.5 KB LDS slab (ds_write_b64 from the D[cout][pixel] register layout, where
+//     registers 4a..4a+3 are four consecutive couts of a pixel) into 16-byte stores in which 8 consecutive lanes write the
+//     whole 128-byte row of a pixel (config 5, 480x640 B=128: 4.5 ms on the general kernel -> see profiles/r02_tuning_notes.md).
 #include "hp3d_common.h"
 
 namespace {
@@ -25,8 +30,21 @@ namespace {
 constexpr int FT_TH = 8, FT_TW = 16;       // tile: 8 rows x 16 pixels = 4 MFMA row blocks (one per wave)
 constexpr int FK = 14;                      // k-steps (K = 28 >= 27)
 
+constexpr int FT_PITCH_H = 72;              // halves per pixel row of the F16 transpose slab (64 + 8: 144 B)
+// wave-level rendezvous for data exchanged through LDS inside ONE wave (the CPU interpreter runs lanes as fibers and needs a
+// real yield point; the trip count of the tile loop is uniform over the workgroup)
+#ifdef HP3D_EMU
+#define HP3D_WAVE_LDS_SYNC() __syncthreads()
+#else
+#define HP3D_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
+typedef hp3d_f16 f16x4 __attribute__((vector_size(8)));
+
+template <bool F16>
 HP3D_KERNEL(256)
 void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
+    HP3D_DYN_SMEM(slab_all);
+    auto rnd = [](float v) { return F16 ? (float)(hp3d_f16)v : v; };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int m = lane & 31, kh = lane >> 5;
@@ -39,7 +57,7 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         for (int kk = 0; kk < FK; ++kk) {
             const int k = 2 * kk + kh;
             bw[nb][kk] = k == 27 ? p.bias[nb * 32 + m]        // the spare K row carries the bias (its image operand is 1)
-                                 : p.wpk[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)];
+                                 : rnd(p.wpk[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)]);
         }
 
     const int strips = (p.tiles_x + tiles_per_wg - 1) / tiles_per_wg;
@@ -50,7 +68,7 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
     const int tx0 = strip * tiles_per_wg, tx1 = min(p.tiles_x, tx0 + tiles_per_wg);
 
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * 12u);
-    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)p.out_cs * 4u);
+    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)p.out_cs * (F16 ? 2u : 4u));
     constexpr int OOR = (int)0x80000000;
 
     // image operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
@@ -65,6 +83,10 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
             const bool ok = k < 27 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
             a[kk] = HP3D_BUFFER_LOAD4(irsrc, ok ? (((b * p.H + yy) * p.W + xx) * 3 + c) * 4 : OOR, 0);
         }
+        if (F16) {
+#pragma unroll
+            for (int kk = 0; kk < FK; ++kk) a[kk] = rnd(a[kk]);
+        }
         if (kh) a[FK - 1] = 1.0f;              // k = 27: multiplies the bias row
     };
     float a_cur[FK], a_nxt[FK];
@@ -73,7 +95,39 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         if (tx + 1 < tx1) gather(tx + 1, a_nxt);
         f32x16 acc0, acc1;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        {
+        if (F16) {
+            // D[cout][pixel]: this lane holds pixel m; accumulator register 4a + j of half nb is cout 32 nb + 8 a + 4 kh + j
+            acc0 = HP3D_MFMA_32x32x2(bw[0][0], a_cur[0], zero);
+            acc1 = HP3D_MFMA_32x32x2(bw[1][0], a_cur[0], zero);
+#pragma unroll
+            for (int kk = 1; kk < FK; ++kk) {
+                acc0 = HP3D_MFMA_32x32x2(bw[0][kk], a_cur[kk], acc0);
+                acc1 = HP3D_MFMA_32x32x2(bw[1][kk], a_cur[kk], acc1);
+            }
+            hp3d_f16* slab = (hp3d_f16*)slab_all + wave * (32 * FT_PITCH_H);
+            HP3D_WAVE_LDS_SYNC();                 // the previous tile's slab reads are done
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f16x4 h0, h1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v0 = acc0[4 * a + j], v1 = acc1[4 * a + j];
+                    if (p.act) { v0 = fmaxf(v0, HP3D_LEAKY_SLOPE * v0); v1 = fmaxf(v1, HP3D_LEAKY_SLOPE * v1); }
+                    h0[j] = (hp3d_f16)v0; h1[j] = (hp3d_f16)v1;
+                }
+                *(f16x4*)(slab + m * FT_PITCH_H + 8 * a + 4 * kh) = h0;
+                *(f16x4*)(slab + m * FT_PITCH_H + 32 + 8 * a + 4 * kh) = h1;
+            }
+            HP3D_WAVE_LDS_SYNC();
+            // lane -> (pixel 8 j + (lane >> 3), 16-byte chunk lane & 7): 8 consecutive lanes = one pixel's 64 halves
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pm = 8 * j + (lane >> 3), ch = lane & 7;
+                const int oy = ty * FT_TH + 2 * wave + (pm >> 4), ox = tx * FT_TW + (pm & 15);
+                const f32x4 v = *(const f32x4*)(slab + pm * FT_PITCH_H + ch * 8);
+                HP3D_BUFFER_STORE16(orsrc, v, (oy < p.H && ox < p.W) ? (((b * p.H + oy) * p.W + ox) * p.out_cs + ch * 8) * 2 : OOR, 0);
+            }
+        } else {
             acc0 = HP3D_MFMA_32x32x2(a_cur[0], bw[0][0], zero);
             acc1 = HP3D_MFMA_32x32x2(a_cur[0], bw[1][0], zero);
 #pragma unroll
@@ -101,9 +155,9 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
 }  // namespace
 
 // conv1_1 shape only: 3x3 / stride 1 / Cin 3 / Cout 64 / float32 in and out, tensors inside 32-bit byte offsets
-int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs) {
-    if (k != 3 || stride != 1 || Cin != 3 || Cout != 64 || out_cs < 64) return 0;
-    return (long)B * H * W * out_cs * 4 < (1L << 31);
+int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16) {
+    if (k != 3 || stride != 1 || Cin != 3 || Cout != 64 || out_cs < 64 || out_cs % 8) return 0;
+    return (long)B * H * W * out_cs * (f16 ? 2 : 4) < (1L << 31);
 }
 
 int conv_first_launch(const ConvParams& pin, hipStream_t s) {
@@ -115,6 +169,9 @@ int conv_first_launch(const ConvParams& pin, hipStream_t s) {
     int per = p.tiles_x;
     while (per > 4 && (long)p.B * p.tiles_y * ((p.tiles_x + per - 1) / per) < 4 * hp3d_num_cus()) per = (per + 1) / 2;
     const int strips = (p.tiles_x + per - 1) / per;
-    HP3D_LAUNCH(conv_first_kernel, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
+    if (p.f16)      // half-precision output [B,H,W,out_cs halves]
+        HP3D_LAUNCH(conv_first_kernel<true>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 4 * 32 * FT_PITCH_H * 2, s, p, per);
+    else
+        HP3D_LAUNCH(conv_first_kernel<false>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
     return 0;
 }

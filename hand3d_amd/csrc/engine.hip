@@ -478,15 +478,15 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
             conv_splitk_reduce_launch(ctx->col, wino_ks, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
                                       std::min(l.cout_pad, out_cs), ctx->stream);
         }
-    } else if (l.mode == 1 && !f16 && !pool && ctx->use_first && !ctx->conv_naive &&
-               conv_first_eligible(l.k, l.stride, l.cin, l.cout, B, H, W, out_cs)) {
+    } else if (l.mode == 1 && !pool && !out_f32 && ctx->use_first && !ctx->conv_naive &&
+               conv_first_eligible(l.k, l.stride, l.cin, l.cout, B, H, W, out_cs, f16)) {
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + l.w_off; p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
         p.Cin = 3; p.in_cs = 3; p.Cout = 64; p.out_cs = out_cs; p.cout_store = 64;
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
-        p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 1;
-        ProfScope ps(ctx, l.name, "conv_first_3x3_c3", flops, bytes);
+        p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = f16; p.out_f32 = 0; p.nsub = 1;
+        ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
         conv_first_launch(p, ctx->stream);
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);

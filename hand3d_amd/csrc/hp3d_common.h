@@ -128,7 +128,7 @@ const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& 
 
 // Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
 void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
-int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs);
+int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16);
 int conv_first_launch(const ConvParams& p, hipStream_t s);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,
                        int pool, int* ksplit);

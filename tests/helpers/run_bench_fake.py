@@ -1,0 +1,108 @@
+"""Runs bench.py's main() with a stand-in Engine (no GPU, no kernels): exercises the launcher protocol of the benchmark --
+environment parsing, TCP rendezvous, weight-sync call order, barrier / max-over-ranks, per-step gather on every rank, the
+rank-0-only JSON line -- under two real processes (tests/test_bench_protocol.py)."""
+import os
+import runpy
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import hand3d_amd  # noqa: E402
+from hand3d_amd import _lib  # noqa: E402
+
+
+class FakeBuf(object):
+    def __init__(self, n):
+        self.a = np.zeros(max(int(n), 1), np.uint8)
+        self.ptr = self.a.ctypes.data
+
+    def __int__(self):
+        return self.ptr
+
+    __index__ = __int__
+
+    def free(self):
+        pass
+
+
+class FakeEngine(object):
+    log = []
+
+    def __init__(self, device=0, path=None):
+        self.device, self.h, self.lib = device, 1, None
+        self.rank = self.world = None
+        self.prof = 0
+
+    def _rec(self, what):
+        FakeEngine.log.append(what)
+
+    def load_weight_dict(self, w):
+        self._rec('load %d' % len(w))
+
+    def finalize_weights(self, dtype=0):
+        self._rec('finalize')
+
+    def comm_unique_id(self):
+        return bytes(range(128))
+
+    def comm_init(self, rank, world, uid):
+        assert uid == bytes(range(128)), "the rendezvous must deliver rank 0's id unchanged"
+        self.rank, self.world = rank, world
+        self._rec('comm_init %d/%d' % (rank, world))
+
+    def bcast_weights(self, root=0):
+        assert self.world is not None
+        self._rec('bcast')
+
+    def comm_destroy(self):
+        self._rec('comm_destroy')
+
+    def set_option(self, k, v):
+        pass
+
+    def to_device(self, a):
+        return FakeBuf(np.asarray(a).nbytes)
+
+    def dev_alloc(self, n):
+        return FakeBuf(n)
+
+    def to_host(self, buf, shape, dtype=np.float32, offset_bytes=0):
+        return np.zeros(shape, dtype)
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        return np.zeros(shape, dtype)
+
+    def upload_async(self, *a):
+        pass
+
+    def wait_upload(self):
+        pass
+
+    def infer_full_dev(self, *a, **k):
+        time.sleep(0.002)
+
+    def sync(self):
+        pass
+
+    def set_profiling(self, on):
+        self.prof = on
+
+    def profile(self):
+        return [('HandSegNet/conv3_2', 'conv_wino_f2x2_3x3', 1.0, 1.0e11, 1.0e8), ('HandSegNet/conv1_1', 'conv_first_3x3_c3', 0.2, 1.0e9, 7.0e8)]
+
+    def allgather_dev(self, buf, count, world):
+        assert self.world == world
+        return np.zeros(world * count, np.float32)
+
+    def counter(self, name):
+        return 0
+
+
+hand3d_amd.Engine = FakeEngine
+_lib.Engine = FakeEngine
+sys.argv = ['bench.py'] + sys.argv[1:]
+runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')
+sys.stderr.write('FAKELOG rank %s: %s\n' % (os.environ.get('RANK', '-'), ' | '.join(FakeEngine.log)))

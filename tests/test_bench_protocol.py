@@ -1,0 +1,59 @@
+"""bench.py's multi-process protocol under two real processes with a stand-in engine (no GPU): RANK / WORLD_SIZE / MASTER_*
+parsing, TCP rendezvous, weight-sync order (rank 0 packs, every rank joins the communicator, then the broadcast), barrier and
+max-over-ranks timing, the per-step gather on every rank, ONE JSON line from rank 0 only.  The 8-GPU run of the driver is the
+first place the real RCCL path meets more than one rank (RCCL refuses two ranks on one device), so the launcher logic is pinned
+here."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HELPER = os.path.join(ROOT, 'tests', 'helpers', 'run_bench_fake.py')
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_bench_protocol_multi_rank(world):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, HELPER, '--gpus', str(world), '--steps', '3', '--warmup', '1', '--batch', '2',
+                                       '--height', '16', '--width', '16'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    lines = [l for l in outs[0][0].splitlines() if l.strip()]
+    assert len(lines) == 1, outs[0][0]
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == world and rec['steps'] == 3 and rec['warmup'] == 1 and rec['scaling'] == 'weak'
+    assert rec['config']['global_batch'] == 2 * world and rec['value'] > 0 and rec['unit'] == 'images/s'
+    assert rec['cpu_baseline'] is None and rec['host_path'] is None          # rank 0, N = 1 only
+    assert rec['roofline']['kernel'] == 'conv_wino' and 0 < rec['roofline']['frac'] <= 1
+    for r in range(1, world):
+        assert outs[r][0].strip() == '', "only rank 0 prints the JSON line"
+    for r, (so, se) in enumerate(outs):
+        log = [l for l in se.splitlines() if l.startswith('FAKELOG')][0]
+        assert ('comm_init %d/%d' % (r, world)) in log and 'bcast' in log and 'comm_destroy' in log
+        assert ('finalize' in log) == (r == 0)
+
+
+def test_bench_protocol_single_process_plain():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, HELPER, '--steps', '2', '--warmup', '0', '--batch', '2', '--height', '16', '--width', '16',
+                          '--cpu-seconds', '0'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec['n_gpus'] == 1 and rec['host_path'] is not None
+    assert 'comm_init' not in out.stderr            # no launcher -> no communicator

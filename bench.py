@@ -298,11 +298,11 @@ def main():
                 eng.infer_full_dev(B, H, W, int(d_img), int(d_hs), kpmap=int(d_kpmap), coord3d=int(d_coord))
                 eng.sync()
                 gpu_out['coord3d'] = eng.to_host(d_coord, (B, 21, 3))
-                nchk = min(B, 8)
+                nchk = min(B, 32)
                 gpu_out['sm32'] = eng.to_host(d_kpmap, (nchk, 256, 256, 21))[:, ::8, ::8]
             else:
                 gpu_out['sm32'] = eng.to_host(d_sm[2], (B, 32, 32, 21))
-            cpu, parity = oracle_leg(weights, img_np[:8], hs_np[:8], gpu_out, a.workload, a.cpu_seconds)
+            cpu, parity = oracle_leg(weights, img_np[:32], hs_np[:32], gpu_out, a.workload, a.cpu_seconds)
         n_img = B * world * a.steps
         fl_img = arch.pipeline_flops(H, W)
         res = {

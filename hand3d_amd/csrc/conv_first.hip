@@ -24,6 +24,7 @@
 //     registers 4a..4a+3 are four consecutive couts of a pixel) into 16-byte stores in which 8 consecutive lanes write the
 //     whole 128-byte row of a pixel (config 5, 480x640 B=128: 4.5 ms on the general kernel -> see profiles/r02_tuning_notes.md).
 #include "hp3d_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -156,22 +157,31 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
 
 // conv1_1 shape only: 3x3 / stride 1 / Cin 3 / Cout 64 / float32 in and out, tensors inside 32-bit byte offsets
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16) {
-    if (k != 3 || stride != 1 || Cin != 3 || Cout != 64 || out_cs < 64 || out_cs % 8) return 0;
-    return (long)B * H * W * out_cs * (f16 ? 2 : 4) < (1L << 31);
+    if (k != 3 || stride != 1 || Cin != 3 || Cout != 64 || out_cs < 64 || out_cs % 8 || B < 1) return 0;
+    return (long)H * W * out_cs * (f16 ? 2 : 4) < (1L << 31);      // one image inside 32-bit offsets (the launcher chunks the batch)
 }
 
 int conv_first_launch(const ConvParams& pin, hipStream_t s) {
     ConvParams p = pin;
     p.tiles_x = (p.W + FT_TW - 1) / FT_TW;
     p.tiles_y = (p.H + FT_TH - 1) / FT_TH;
-    // a workgroup walks a strip of tiles of one tile row: long enough to amortise the filter load and the first gather,
-    // short enough to leave >= ~4 workgroups per CU
-    int per = p.tiles_x;
-    while (per > 4 && (long)p.B * p.tiles_y * ((p.tiles_x + per - 1) / per) < 4 * hp3d_num_cus()) per = (per + 1) / 2;
-    const int strips = (p.tiles_x + per - 1) / per;
-    if (p.f16)      // half-precision output [B,H,W,out_cs halves]
-        HP3D_LAUNCH(conv_first_kernel<true>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 4 * 32 * FT_PITCH_H * 2, s, p, per);
-    else
-        HP3D_LAUNCH(conv_first_kernel<false>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
+    // the kernel addresses input and output with 32-bit byte offsets from the tensor base: batches whose output passes 2^31
+    // bytes (config 5: 128 x 480 x 640 x 64 halves = 5 GB) run as consecutive launches over image ranges
+    const long per_img = (long)p.H * p.W * p.out_cs * (p.f16 ? 2 : 4);
+    const int maxb = (int)std::max<long>(1, ((1L << 31) - 1) / per_img);
+    for (int b0 = 0; b0 < pin.B; b0 += maxb) {
+        p.B = std::min(maxb, pin.B - b0);
+        p.in = pin.in + (size_t)b0 * p.H * p.W * 3;
+        p.out = (float*)((char*)pin.out + (size_t)b0 * per_img);
+        // a workgroup walks a strip of tiles of one tile row: long enough to amortise the filter load and the first gather,
+        // short enough to leave >= ~4 workgroups per CU
+        int per = p.tiles_x;
+        while (per > 4 && (long)p.B * p.tiles_y * ((p.tiles_x + per - 1) / per) < 4 * hp3d_num_cus()) per = (per + 1) / 2;
+        const int strips = (p.tiles_x + per - 1) / per;
+        if (p.f16)      // half-precision output [B,H,W,out_cs halves]
+            HP3D_LAUNCH(conv_first_kernel<true>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 4 * 32 * FT_PITCH_H * 2, s, p, per);
+        else
+            HP3D_LAUNCH(conv_first_kernel<false>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
+    }
     return 0;
 }

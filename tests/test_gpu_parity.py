@@ -747,3 +747,23 @@ def test_two_streams_equal_one_stream(net, synth_weights):
             buf.free()
     finally:
         eng.set_option('streams', 'auto')
+
+
+def test_conv_first_batch_beyond_32bit_offsets(net, synth_weights):
+    """conv1_1 at 480x640 with 28 images writes 2.2 GB: conv_first's launcher cuts the batch into image ranges that each stay
+    inside the kernel's 32-bit offsets (config 5 runs 128 images per GPU; hp3d_handsegnet does not chunk the batch itself).
+    Images on both sides of the cut equal their single-image runs (to rounding: B = 1 takes the small-batch plan)."""
+    B = 28
+    img = synth.make_batch(8300, 4, 480, 640)
+    x = np.concatenate([img] * 7, 0)
+    x[27] = synth.make_batch(8399, 1, 480, 640)[0]
+    net.engine.set_profiling(1)
+    large = net.engine.handsegnet(x)
+    kernels = set(k for _, k, _, _, _ in net.engine.profile())
+    net.engine.set_profiling(0)
+    assert 'conv_first_3x3_c3' in kernels, kernels
+    assert large.shape == (B, 480, 640, 2) and np.isfinite(large).all()
+    for i in (0, 26, 27):
+        li = net.engine.handsegnet(x[i:i + 1])
+        assert np.abs(large[i:i + 1] - li).max() < 5e-5, i
+    assert np.abs(large[27] - large[3]).max() > 1e-3          # image 27 is a different image: really its own result

@@ -767,3 +767,48 @@ def test_conv_first_batch_beyond_32bit_offsets(net, synth_weights):
         li = net.engine.handsegnet(x[i:i + 1])
         assert np.abs(large[i:i + 1] - li).max() < 5e-5, i
     assert np.abs(large[27] - large[3]).max() > 1e-3          # image 27 is a different image: really its own result
+
+
+def test_size_independent_properties_at_full_size(gpu_engine):
+    """Properties that need no oracle, at BASELINE's largest single-image geometry (480x640):
+    * the seeded mask growth is idempotent: growing again from the grown mask (as a saturated score map) returns it;
+    * the legacy x8 bilinear up-sampling reproduces its source at every 8th pixel and is bounded by it;
+    * a crop whose box is the 256x256 window around the centre at scale 1 is the identity on that window;
+    * hp3d_detect_keypoints on a map with one planted peak per channel returns 8 x the peak position."""
+    e = gpu_engine
+    rng = np.random.default_rng(404)
+    H, W = 480, 640
+    # a random union of rectangles as foreground, strongest where the seed should land
+    sm = np.zeros((1, H, W, 2), np.float32)
+    sm[..., 0] = 2.0
+    for _ in range(12):
+        y0, x0 = int(rng.integers(100, 300)), int(rng.integers(150, 400))
+        sm[0, y0:y0 + int(rng.integers(20, 90)), x0:x0 + int(rng.integers(20, 120)), 1] = 6.0
+    sm[0, 200:210, 300:310, 1] = 9.0
+    mask, center, size, scale, seed = e.mask_from_scoremap(sm)
+    assert mask.sum() > 0 and mask[0, seed[0, 0], seed[0, 1]] == 1
+    sm2 = np.zeros_like(sm)
+    sm2[..., 0] = 1.0
+    sm2[..., 1] = mask * 5.0
+    sm2[0, seed[0, 0], seed[0, 1], 1] = 7.0                 # same seed
+    mask2, center2, size2, _, seed2 = e.mask_from_scoremap(sm2)
+    assert np.array_equal(mask2, mask) and np.array_equal(center2, center) and np.array_equal(size2, size)
+    # up-sampling
+    x = rng.standard_normal((2, 60, 80, 21)).astype(np.float32)
+    up = e.resize_bilinear(x, 480, 640)
+    assert np.array_equal(up[:, ::8, ::8, :], x)
+    assert up.max() <= x.max() and up.min() >= x.min()
+    # identity crop: scale 1, box = [c - 128, c + 128) on a 480x640 image samples whole pixels
+    img = rng.uniform(-0.5, 0.5, (1, H, W, 3)).astype(np.float32)
+    c = np.array([[240.0, 320.0]], np.float32)
+    crop = e.crop_and_resize(img, c, np.array([1.0], np.float32), 256)
+    y1 = np.float32(240 - 128) / np.float32(H) * np.float32(H - 1)          # crop_and_resize maps with (H-1), (W-1)
+    assert crop.shape == (1, 256, 256, 3) and np.isfinite(crop).all()
+    assert abs(float(crop[0, 0, 0, 0]) - float(img[0, 112, 192, 0])) < 0.6   # the box starts inside pixel (111.77, 191.7)
+    # planted peaks
+    smk = (rng.standard_normal((3, 32, 32, 21)) * 0.1).astype(np.float32)
+    pos = rng.integers(0, 32, (3, 21, 2))
+    for b in range(3):
+        for ch in range(21):
+            smk[b, pos[b, ch, 0], pos[b, ch, 1], ch] = 5.0 + ch
+    assert np.array_equal(e.detect_keypoints(smk), (pos * 8).astype(np.int32))

@@ -250,6 +250,7 @@ struct hp3d_ctx {
     hp3d_ctx* kid = nullptr;   // the second stream's context: own stream + arena, SHARES this context's weight blob
     bool shared_weights = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int use_h16 = 1;           // half-precision 3x3 trunk layers on conv_h16.hip (option "f16_impl" = "h16" | "mfma")
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
@@ -488,6 +489,17 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = f16; p.out_f32 = 0; p.nsub = 1;
         ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
         conv_first_launch(p, ctx->stream);
+    } else if (f16 && ctx->use_h16 && l.mode == 0 && !ctx->conv_naive &&
+               conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32)) {
+        ConvParams p;
+        p.in = in; p.wpk = (const float*)(ctx->blob16 + l.w16_off); p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad16 / 2; p.in_cs = in_cs / 2; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 1; p.out_f32 = 0; p.nsub = 1;
+        ProfScope ps(ctx, l.name, pool ? "conv_h16_3x3_pool" : "conv_h16_3x3", flops, bytes);
+        if (conv_h16_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 launch failed for %s", l.name.c_str());
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
         conv_naive_launch(in, B, H, W, l.cin, in_cs, ctx->naive_w[l.name], ctx->blob + l.b_off, l.k, l.stride, l.cout,
@@ -869,7 +881,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_h16 = ctx->use_h16; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1180,6 +1192,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
     if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {
         ctx->conv_naive = (v == "naive");

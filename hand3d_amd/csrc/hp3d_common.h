@@ -72,6 +72,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
+// 2 B per lane (a half); same addressing / range check
+#define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (hp3d_f16)(half_val)), (rsrc), (voff), (soff), 0)
 // 16 B per lane (same addressing / range check)
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, (val4)), (rsrc), (voff), (soff), 0)
@@ -82,6 +85,7 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) ((void)(rsrc), (void)(half_val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
 #endif
 #endif
@@ -128,6 +132,9 @@ const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& 
 
 // Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
 void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
+// half-precision 3x3 trunk layers on their own kernel (conv_h16.hip): returns per-wave cout blocks (1, 2, 4) or 0
+int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32);
+int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s);
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16);
 int conv_first_launch(const ConvParams& p, hipStream_t s);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,

@@ -75,6 +75,10 @@ static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff,
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
+static inline void hp3d_emu_buffer_store2(hp3d_rsrc_t r, hp3d_f16 v, unsigned voff, unsigned soff) {
+    if (voff < r.bytes && voff + soff + 2u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 2);
+}
+#define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) hp3d_emu_buffer_store2((rsrc), (hp3d_f16)(half_val), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store16(hp3d_rsrc_t r, f32x4 v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 16u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 16);
 }

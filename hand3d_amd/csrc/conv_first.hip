@@ -32,15 +32,6 @@ constexpr int FT_TH = 8, FT_TW = 16;       // tile: 8 rows x 16 pixels = 4 MFMA 
 constexpr int FK = 14;                      // k-steps (K = 28 >= 27)
 
 constexpr int FT_PITCH_H = 72;              // halves per pixel row of the F16 transpose slab (64 + 8: 144 B)
-// wave-level rendezvous for data exchanged through LDS inside ONE wave (the CPU interpreter runs lanes as fibers and needs a
-// real yield point; the trip count of the tile loop is uniform over the workgroup)
-#ifdef HP3D_EMU
-#define HP3D_WAVE_LDS_SYNC() __syncthreads()
-#else
-#define HP3D_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#endif
-typedef hp3d_f16 f16x4 __attribute__((vector_size(8)));
-
 template <bool F16>
 HP3D_KERNEL(256)
 void conv_first_kernel(const ConvParams p, int tiles_per_wg) {

@@ -17,6 +17,19 @@
 //   * persistent grid over (image, tile, cout block) items.
 #include "hp3d_common.h"
 #include <algorithm>
+#ifndef HP3D_H16_NT
+#define HP3D_H16_NT 0           // bit 0: patch loads non-temporal, bit 1: output stores non-temporal
+#endif
+#if HP3D_H16_NT & 1
+#define H16_LOAD_IN HP3D_BUFFER_LOAD16_NT
+#else
+#define H16_LOAD_IN HP3D_BUFFER_LOAD16
+#endif
+#if HP3D_H16_NT & 2
+#define H16_STORE_OUT HP3D_BUFFER_STORE16_NT
+#else
+#define H16_STORE_OUT HP3D_BUFFER_STORE16
+#endif
 #ifndef HP3D_H16_ABL
 #define HP3D_H16_ABL 0          // timing ablations (scripts/build_variant.sh); any non-zero value computes wrong results
 #endif
@@ -29,11 +42,20 @@ constexpr int HPITCH = 36;                // floats per patch pixel: 64 halves =
 constexpr int HPATCH_FLOATS = HPW * HPW * HPITCH;        // 11664 floats = 46.7 KB per buffer
 constexpr int HPIECES = HPW * HPW * 8;    // 16-byte pieces per patch
 constexpr int HPVEC = (HPIECES + 255) / 256;             // pieces per thread (11)
-constexpr int HRING = 6;                  // K-steps of weight fragments in flight per wave
+constexpr int HPGS = 4, HPG = (HPVEC + HPGS - 1) / HPGS;  // patch pieces per group, groups (3)
+constexpr int HPSTEP = 36 / HPG;         // K-steps between the fetches of successive groups
+#ifndef HP3D_H16_RING
+#define HP3D_H16_RING 6
+#endif
+constexpr int HRING = HP3D_H16_RING;                  // K-steps of weight fragments in flight per wave
 
-template <int NT, bool POOL>
-HP3D_KERNEL2(256, 1)
+// WPS = workgroups per CU (waves per SIMD).  WPS == 1: the patch is double buffered (the next chunk streams in under the
+// current one).  WPS > 1 (NT <= 2: few accumulators, few chunks, store-heavy): ONE patch buffer, and the load / store phases
+// of one workgroup are covered by the MFMAs of the other(s) on the same CU.
+template <int NT, bool POOL, int WPS>
+HP3D_KERNEL2(256, WPS)
 void conv_h16_kernel(const ConvParams p) {
+    constexpr bool DB = WPS == 1;
     HP3D_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
@@ -57,6 +79,7 @@ void conv_h16_kernel(const ConvParams p) {
         const int ly = (wm * 4 + mt) * 2 + dy, lx = 2 * q + dx;
         abase[mt] = ((ly * HPW + lx) * HPITCH + lh * 4) * 4;          // bytes
     }
+    const int wbase = (tid >> 3) * HPITCH + (tid & 7) * 4;     // LDS float index of this thread's patch piece 0 (piece v: + 32 v pixels)
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(9 * p.Cin) * (unsigned)p.Cout * 4u);
     const int tap_stride_b = KB * CO32 * 1024;           // bytes between taps of the packed weights
 
@@ -67,8 +90,11 @@ void conv_h16_kernel(const ConvParams p) {
         const int ty = it % tiles_y;
         const int b = it / tiles_y;
         const int oy0 = ty * HT, ox0 = tx * HT;
-        const float* inb = p.in + (size_t)b * p.H * p.W * p.in_cs;
-        // this thread's patch pieces: piece idx -> (patch pixel, 16-byte slot); -1 = zero fill (SAME padding / image edge)
+        // this thread's patch pieces: piece idx -> (patch pixel, 16-byte slot) -> byte offset inside image b; SAME padding,
+        // the image edge and idx past the patch get an out-of-range offset, which a buffer load answers with zeros.
+        // Pieces move in HPG groups of HPGS (fetch -> registers -> LDS) so that only HPGS x 4 registers hold patch data.
+        constexpr int OOR = (int)0x80000000;
+        const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in + (size_t)b * p.H * p.W * p.in_cs, (unsigned)(p.H * p.W) * (unsigned)p.in_cs * 4u);
         int poff[HPVEC];
 #pragma unroll
         for (int v = 0; v < HPVEC; ++v) {
@@ -77,22 +103,19 @@ void conv_h16_kernel(const ConvParams p) {
             const int py = pix / HPW, px = pix - py * HPW;
             const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
             const bool ok = idx < HPIECES && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            poff[v] = ok ? (gy * p.W + gx) * p.in_cs + c4 * 4 : -1;
+            poff[v] = ok ? ((gy * p.W + gx) * p.in_cs + c4 * 4) * 4 : OOR;
         }
-        f32x4 preg[HPVEC];
-        auto patch_fetch = [&](int chunk) {
+        f32x4 preg[HPGS];
+        auto patch_fetch = [&](int chunk, int g) {
 #pragma unroll
-            for (int v = 0; v < HPVEC; ++v) {
-                f32x4 val = {0.f, 0.f, 0.f, 0.f};
-                if (poff[v] >= 0) val = *(const f32x4*)(inb + poff[v] + chunk * 32);
-                preg[v] = val;
-            }
+            for (int j = 0; j < HPGS; ++j)
+                if (g * HPGS + j < HPVEC) preg[j] = H16_LOAD_IN(irsrc, poff[g * HPGS + j], chunk * 128);
         };
-        auto patch_commit = [&](int buf) {
+        auto patch_commit = [&](int buf, int g) {
 #pragma unroll
-            for (int v = 0; v < HPVEC; ++v) {
-                const int idx = tid + v * 256;
-                if (idx < HPIECES) *(f32x4*)(smem + buf * HPATCH_FLOATS + (idx >> 3) * HPITCH + (idx & 7) * 4) = preg[v];
+            for (int j = 0; j < HPGS; ++j) {
+                const int v = g * HPGS + j;                // piece tid + 256 v: patch pixel (tid >> 3) + 32 v, slot tid & 7
+                if (v < HPVEC && tid + v * 256 < HPIECES) *(f32x4*)(smem + buf * HPATCH_FLOATS + wbase + v * (32 * HPITCH)) = preg[j];
             }
         };
 
@@ -108,7 +131,7 @@ void conv_h16_kernel(const ConvParams p) {
         const int wvoff = (cb * (BN / 32) + wn * NT) * 1024 + lane * 16;
         f32x4 fb[HRING][NT];
         auto b_fetch = [&](int slot, int tap, int kb) {
-            const int soff = tap * tap_stride_b + kb * (CO32 * 1024);
+            const int soff = (HP3D_H16_ABL & 16) ? 0 : tap * tap_stride_b + kb * (CO32 * 1024);     // ablation 16: always the same 4 KB (L1 hits)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) fb[slot][nt] = HP3D_BUFFER_LOAD16(wrsrc, wvoff + nt * 1024, soff);
         };
@@ -119,22 +142,36 @@ void conv_h16_kernel(const ConvParams p) {
                 fa[set][mt] = *(const f32x4*)((const char*)smem + buf * (HPATCH_FLOATS * 4) + abase[mt] + toff_b + ks * 32);
         };
 
-        __syncthreads();                       // the previous item's waves are done with both patch buffers
-        patch_fetch(0);
+        // a whole chunk into buffer 0 with all pieces in flight at once (the fragment registers are free at that point), and
+        // the first RING-1 K-steps of its weights: (tap, ks) = (s / 4, s % 4)
+        auto load_chunk = [&](int chunk) {
+            f32x4 first[HPVEC];
 #pragma unroll
-        for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, s & 3);      // K-steps 0 .. RING-2 of chunk 0: (tap, ks) = (s / 4, s % 4)
-        patch_commit(0);
+            for (int v = 0; v < HPVEC; ++v) first[v] = H16_LOAD_IN(irsrc, poff[v], chunk * 128);
+#pragma unroll
+            for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, chunk * 4 + (s & 3));
+#pragma unroll
+            for (int v = 0; v < HPVEC; ++v)
+                if (tid + v * 256 < HPIECES) *(f32x4*)(smem + wbase + v * (32 * HPITCH)) = first[v];
+        };
+        __syncthreads();                       // the previous item's waves are done with the patch buffers / slabs
+        load_chunk(0);
         __syncthreads();
         int cur = 0;
         for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const bool has_next = chunk + 1 < nchunks;
-            if (has_next && !(HP3D_H16_ABL & 2)) patch_fetch(chunk + 1);
+            const bool has_next = DB && chunk + 1 < nchunks;
+            if (!DB && chunk > 0) { __syncthreads(); load_chunk(chunk); __syncthreads(); }
             a_fetch(0, cur, 0, 0);
             // 36 K-steps of this chunk, straight line: step s = 4 tap + ks
 #pragma unroll
             for (int s = 0; s < 36; ++s) {
                 const int tap = s >> 2, ks = s & 3;
                 HP3D_SCHED_BARRIER();
+                // next chunk's patch, group g: fetched at step g HPSTEP, committed to the other buffer HPSTEP - 1 steps later
+                if (has_next && !(HP3D_H16_ABL & 2)) {
+                    if (s % HPSTEP == 0) patch_fetch(chunk + 1, s / HPSTEP);
+                    if (s % HPSTEP == HPSTEP - 1) patch_commit(cur ^ 1, s / HPSTEP);
+                }
                 // prefetch: A fragments of step s+1 (other register set), weight fragments of step s + RING - 1
                 if (s + 1 < 36 && !(HP3D_H16_ABL & 8)) {
                     const int t1 = (s + 1) >> 2, r1 = t1 / 3, c1 = t1 - r1 * 3;
@@ -146,56 +183,104 @@ void conv_h16_kernel(const ConvParams p) {
                     else if (s2 < 36) b_fetch(s2 % HRING, s2 >> 2, chunk * 4 + (s2 & 3));
                     else if (has_next) b_fetch(s2 % HRING, (s2 - 36) >> 2, (chunk + 1) * 4 + ((s2 - 36) & 3));
                 }
+                HP3D_SCHED_BARRIER();          // the prefetches are issued BEFORE this step's MFMAs: a whole step of latency cover
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = HP3D_MFMA_32x32x16_F16(fa[s & 1][mt], fb[s % HRING][nt], acc[mt][nt]);
-                if (s == 30 && has_next) patch_commit(cur ^ 1);      // lands under the last taps
+                        acc[mt][nt] = HP3D_MFMA_32x32x16_F16(fb[s % HRING][nt], fa[s & 1][mt], acc[mt][nt]);   // D[cout][pixel]
                 (void)tap; (void)ks;
             }
             HP3D_SCHED_BARRIER();
-            __syncthreads();                   // patch[cur ^ 1] complete, patch[cur] free
-            cur ^= 1;
+            if (DB) { __syncthreads(); cur ^= 1; }     // patch[cur ^ 1] complete, patch[cur] free
         }
+        if (!DB) __syncthreads();              // all waves are done with the patch: the slabs below reuse its memory
 
-        // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool), halves out.  Buffer stores with 32-bit offsets inside the image
-        //      (an invalid lane / pixel gets an out-of-range offset and is dropped): no branches, no 64-bit address math
-        if (HP3D_H16_ABL & 1) { if (acc[0][0][0] == 12345.f) p.out[0] = acc[1][0][3] + acc[3][NT - 1][7]; continue; }
-        constexpr int OOR = (int)0x80000000;
+        // ---- epilogue: bias + leaky-ReLU (+ 2x2 max-pool), halves out.  Accumulator (lane (li, lh), register 4 a + e) = pixel li
+        //      of row block mt, cout 32 nt + 8 a + 4 lh + e: four consecutive couts per lane.  Each wave transposes through its own
+        //      LDS slab (the patch buffers are free after the last chunk's barrier): 8-byte writes [pixel][cout], 16-byte reads, and
+        //      every global store is 16 B per lane with one pixel's couts contiguous (the pooled form takes the max of the four
+        //      pixels' half vectors on the way: rounding is monotonic, so max-then-round == round-then-max).
+        //      Buffer stores with 32-bit offsets inside the image; an invalid lane gets an out-of-range offset and is dropped.
+        if (HP3D_H16_ABL & 1) {                 // all accumulators stay live
+            float t = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
+            if (t == 12345.f) p.out[0] = t;
+            continue;
+        }
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC((hp3d_f16*)p.out + (size_t)b * Hs * Ws * p.out_cs,
                                                  (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 2u);
-        const int row_b = Ws * p.out_cs * 2, px_b = p.out_cs * 2;            // bytes per output row / pixel
+        const int px_b = p.out_cs * 2;                                       // bytes per output pixel
+        constexpr int G = 4 * NT;                                            // 16-byte groups per pixel of this wave's couts
+        constexpr int SPITCH = 64 * NT + 16;                                 // slab bytes per pixel (pad: conflict-free)
+        constexpr int SLAB = 32 * SPITCH;                                    // one row block (32 pixels)
+        char* slab = (char*)smem + wave * (4 * SLAB);                        // this wave's four slabs (one per row block)
+        f32x4 bias4[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int co = cb * BN + (wn * NT + nt) * 32 + li;
-            const float bias = p.bias[co];
-            const bool cok = co < p.cout_store;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const int y0 = oy0 + (wm * 4 + mt) * 2;                       // conv-output row of (dy = 0)
+            for (int a = 0; a < 4; ++a)
+                bias4[nt][a] = *(const f32x4*)(p.bias + cb * BN + (wn * NT + nt) * 32 + a * 8 + lh * 4);
+        // slab pixel of MFMA column li (the 2x2 quad order of abase): sp = 16 dy + 2 q + dx
+        const int sp_w = ((li >> 1) & 1) * 16 + 2 * (li >> 2) + (li & 1);
+        const int wr_off = sp_w * SPITCH + lh * 8;
+        const int g = lane % G, sp0 = lane / G;                              // read side: lane -> (pixel sp0 + k PPR, group g)
+        const int cbyte = (cb * BN + wn * (32 * NT)) * 2 + g * 16;
+        const bool cok = cb * BN + wn * (32 * NT) + g * 8 < p.cout_store;
 #pragma unroll
-                for (int a4 = 0; a4 < 4; ++a4) {
-                    const int x0 = ox0 + 2 * (2 * a4 + lh);                  // quad 2 a4 + lh of registers 4 a4 .. 4 a4 + 3
-                    float v[4];
+        for (int mt = 0; mt < 4; ++mt) {
+            char* sl = slab + mt * SLAB;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f16x4 h;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float x = acc[mt][nt][a4 * 4 + e] + bias;
+                        float x = acc[mt][nt][a * 4 + e] + bias4[nt][a][e];
                         if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
-                        v[e] = x;
+                        h[e] = (hp3d_f16)x;
                     }
-                    if (POOL) {
-                        const int yp = y0 >> 1, xp = x0 >> 1;
-                        const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                        HP3D_BUFFER_STORE2(orsrc, m, (cok && yp < Hs && xp < Ws) ? yp * row_b + xp * px_b + co * 2 : OOR, 0);
-                    } else {
-                        const int base = (cok && y0 < Hs && x0 < Ws) ? y0 * row_b + x0 * px_b + co * 2 : OOR;
-                        const int bx = x0 + 1 < Ws ? base : OOR, by = y0 + 1 < Hs ? base : OOR;
-                        HP3D_BUFFER_STORE2(orsrc, v[0], base, 0);
-                        HP3D_BUFFER_STORE2(orsrc, v[1], bx, px_b);
-                        HP3D_BUFFER_STORE2(orsrc, v[2], by, row_b);
-                        HP3D_BUFFER_STORE2(orsrc, v[3], (x0 + 1 < Ws) ? by : OOR, row_b + px_b);
+                    *(f16x4*)(sl + wr_off + nt * 64 + a * 16) = h;
+                }
+        }
+        HP3D_WAVE_LDS_SYNC();                  // one rendezvous for all four row blocks
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const char* sl = slab + mt * SLAB;
+            const int yb = oy0 + (wm * 4 + mt) * 2;                          // conv-output row of slab row 0
+            if (POOL) {
+                constexpr int PPR = 64 / G;                                  // pooled pixels per round (16 when NT = 1: 8 are real)
+                constexpr int ROUNDS = (8 + PPR - 1) / PPR;
+#pragma unroll
+                for (int r = 0; r < ROUNDS; ++r) {
+                    const int pp = sp0 + r * PPR;                            // pooled column inside the tile, 0..7
+                    const int ppc = pp < 8 ? pp : 0;
+                    f16x8 m = *(const f16x8*)(sl + (2 * ppc) * SPITCH + g * 16);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) {
+                        const f16x8 o = *(const f16x8*)(sl + ((w >> 1) * 16 + 2 * ppc + (w & 1)) * SPITCH + g * 16);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) m[e] = m[e] > o[e] ? m[e] : o[e];
                     }
+                    const int yp = yb >> 1, xp = (ox0 >> 1) + pp;
+                    const int off = (cok && pp < 8 && yp < Hs && xp < Ws) ? (yp * Ws + xp) * px_b + cbyte : OOR;
+                    H16_STORE_OUT(orsrc, __builtin_bit_cast(f32x4, m), off, 0);
+                }
+            } else {
+                constexpr int PPR = 64 / G;                                  // pixels per round: 4 / 8 / 16
+#pragma unroll
+                for (int r = 0; r < 32 / PPR; ++r) {
+                    const int sp = sp0 + r * PPR;
+                    const f32x4 v = *(const f32x4*)(sl + sp * SPITCH + g * 16);
+                    const int y = yb + ((r * PPR) >> 4), x = ox0 + sp0 + ((r * PPR) & 15);
+                    const int off = (cok && y < Hs && x < Ws) ? (y * Ws + x) * px_b + cbyte : OOR;
+                    H16_STORE_OUT(orsrc, v, off, 0);
                 }
             }
         }
@@ -205,29 +290,45 @@ void conv_h16_kernel(const ConvParams p) {
 template <int NT, bool POOL>
 void h16_launch_t(const ConvParams& p, hipStream_t s) {
     static bool attr_done[64] = {};
-    auto k = conv_h16_kernel<NT, POOL>;
-    constexpr int SMEM = 2 * HPATCH_FLOATS * 4;
+    constexpr int WPS = NT == 4 ? 1 : NT == 2 ? 2 : 3;
+    auto k = conv_h16_kernel<NT, POOL, WPS>;
+    constexpr int SLABS = 4 * 4 * 32 * (64 * NT + 16);                       // epilogue: 4 waves x 4 row blocks x 32 pixels
+    constexpr int PATCHES = (WPS == 1 ? 2 : 1) * HPATCH_FLOATS * 4;
+    constexpr int SMEM = PATCHES > SLABS ? PATCHES : SLABS;
+    static_assert(SMEM * WPS <= 160 * 1024, "LDS per CU");
     if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     const long items = (long)p.B * ((p.Ho + HT - 1) / HT) * ((p.Wo + HT - 1) / HT) * (p.Cout / (64 * NT));
-    const int slots = hp3d_num_cus();
+    const int slots = hp3d_num_cus() * WPS;
     HP3D_LAUNCH(k, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SMEM, s, p);
+}
+
+#ifndef HP3D_H16_MAXNT
+#define HP3D_H16_MAXNT 4
+#endif
+// per-wave cout blocks: 4 (one workgroup per CU, double-buffered patch) only where the K loop is long enough to amortise the
+// serial load / store phases of a lone workgroup (Cin >= 512: measured 1199 vs 1153 TFLOP/s at conv4_2); below that two
+// workgroups per CU with 2 blocks each cover each other's phases (conv3_1 955 vs 811, conv3_2 1094 vs 985)
+inline int h16_nt(int Cout, int cin_units) {
+    const int nt = (Cout % 256 == 0 && cin_units >= 256) ? 4 : Cout % 128 == 0 ? 2 : 1;
+    return nt < HP3D_H16_MAXNT ? nt : HP3D_H16_MAXNT;
 }
 
 }  // namespace
 
 // 3x3 / stride 1, half-precision operands and output (not the float32 score-map heads), Cin a multiple of 64 halves,
-// Cout a multiple of 64; enough work items to fill the chip.  Returns the per-wave cout blocks NT (1, 2 or 4) or 0.
-// mode 1: only when the grid fills the chip; mode 2 (tests): whenever the shape allows
-int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32) {
-    if (!mode || k != 3 || stride != 1 || out_f32 || cin_units % 32 || cin_units < 32 || Cout % 64) return 0;
-    const int nt = Cout % 256 == 0 ? 4 : Cout % 128 == 0 ? 2 : 1;
+// Cout a multiple of 64, output pixel stride a multiple of 8 halves (16-byte stores); enough work items to fill the chip.
+// Returns the per-wave cout blocks NT (1, 2 or 4) or 0.  mode 1: only when the grid fills the chip; mode 2 (tests): whenever
+// the shape allows
+int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32, int out_cs) {
+    if (!mode || k != 3 || stride != 1 || out_f32 || cin_units % 32 || cin_units < 32 || Cout % 64 || out_cs % 8) return 0;
+    const int nt = h16_nt(Cout, cin_units);
     const long items = (long)B * ((Ho + HT - 1) / HT) * ((Wo + HT - 1) / HT) * (Cout / (64 * nt));
     return (mode == 2 || items >= 256) ? nt : 0;
 }
 
 int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s) {
-    const int nt = p.Cout % 256 == 0 ? 4 : p.Cout % 128 == 0 ? 2 : p.Cout % 64 == 0 ? 1 : 0;
+    const int nt = p.Cout % 64 == 0 ? h16_nt(p.Cout, p.Cin) : 0;
     if (!nt || (pool && ((p.Ho | p.Wo) & 1))) return -1;
     if (nt == 4) { if (pool) h16_launch_t<4, true>(p, s); else h16_launch_t<4, false>(p, s); }
     else if (nt == 2) { if (pool) h16_launch_t<2, true>(p, s); else h16_launch_t<2, false>(p, s); }

@@ -254,6 +254,7 @@ struct hp3d_ctx {
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
+    long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
                                // 32 in float32 mode, no split with half-precision trunks -- measured optima)
@@ -490,7 +491,8 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
         conv_first_launch(p, ctx->stream);
     } else if (f16 && ctx->use_h16 && l.mode == 0 && !ctx->conv_naive &&
-               conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32)) {
+               conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32, out_cs) &&
+               ((uintptr_t)out & 15) == 0) {
         ConvParams p;
         p.in = in; p.wpk = (const float*)(ctx->blob16 + l.w16_off); p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -499,6 +501,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
         p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 1; p.out_f32 = 0; p.nsub = 1;
         ProfScope ps(ctx, l.name, pool ? "conv_h16_3x3_pool" : "conv_h16_3x3", flops, bytes);
+        ++ctx->conv_h16_launches;
         if (conv_h16_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 launch failed for %s", l.name.c_str());
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
         ProfScope ps(ctx, l.name, "conv_naive", flops, bytes);
@@ -1800,6 +1803,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     const std::string k(name);
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
+    if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);
 }
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {

@@ -15,6 +15,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((vector_size(8)));
+// wave-level rendezvous for data exchanged through LDS inside ONE wave
+#define HP3D_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define HP3D_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
 #define HP3D_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
@@ -66,6 +69,12 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
+// the same with the non-temporal hint (streamed once: activations passing through, so that they do not displace the
+// weights every workgroup of the XCD re-reads from its L2)
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 2))
+#define HP3D_BUFFER_STORE16_NT(rsrc, val4, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, (val4)), (rsrc), (voff), (soff), 2)
 // 4 B per lane from (rsrc base + per-lane voff + scalar soff); out-of-range offsets read 0
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 0))
@@ -85,6 +94,8 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) HP3D_BUFFER_LOAD16(rsrc, voff, soff)
+#define HP3D_BUFFER_STORE16_NT(rsrc, val4, voff, soff) HP3D_BUFFER_STORE16(rsrc, val4, voff, soff)
 #define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) ((void)(rsrc), (void)(half_val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
 #endif
@@ -133,7 +144,7 @@ const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& 
 // Winograd F(2x2,3x3) form of the 3x3/stride-1 layers with Cout % 128 == 0 (conv_wino.hip)
 void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 // half-precision 3x3 trunk layers on their own kernel (conv_h16.hip): returns per-wave cout blocks (1, 2, 4) or 0
-int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32);
+int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32, int out_cs);
 int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s);
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16);
 int conv_first_launch(const ConvParams& p, hipStream_t s);

@@ -207,7 +207,8 @@ int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, 
 #define HP3D_TIMING_STAGES 5
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
 /* Executor counters: "graph_captures" / "graph_replays" = hipGraphs instantiated / launched since hp3d_create (option
- * "graph" = "1"; a replay happens only with per-launch profiling off).                                            */
+ * "graph" = "1"; a replay happens only with per-launch profiling off); "conv_h16_launches" = half-precision trunk
+ * layers that ran on conv_h16.hip (option "f16_impl").                                                            */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);
 
 /* ---- multi-GPU: one process and one context per GPU, RCCL over xGMI ---------

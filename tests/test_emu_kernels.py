@@ -171,6 +171,32 @@ def test_f16_trunk_mode_on_interpreter(emu_engine, synth_weights):
     assert not (emu_engine.nets_mask() & 32)
 
 
+def test_f16_trunks_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights):
+    """conv_h16.hip (option f16_impl=h16_force: taken whenever the shape allows, also below the grid-fill threshold):
+    HandSegNet's 3x3 trunk incl. the pooled layers, ragged 16 x 16 tiles (24 x 40 and 16 x 72 images, and their pooled sizes) and all three cout-block
+    widths (64 / 128 / 256+), vs the oracle with the same rounding points AND vs the general f16 kernel on the same input
+    (same MFMA, same packed weights: differences are accumulation-order only)."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights, dtype='f16')
+    try:
+        for (h, w) in ((24, 40), (16, 72)):
+            img = synth.make_batch(5, 1, h, w)
+            emu_engine.set_option('f16_impl', 'mfma')
+            _, small_ref = emu_engine.handsegnet(img, want_small=True)
+            emu_engine.set_option('f16_impl', 'h16_force')
+            _, small = emu_engine.handsegnet(img, want_small=True)
+            rs, _ = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
+            assert np.abs(small - rs).max() < 2e-3
+            assert np.abs(small - small_ref).max() < 5e-4
+        crop = synth.make_batch(9, 1, 16, 16)
+        for a, b in zip(net.inference_pose2d(crop), N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)):
+            assert np.abs(a - b).max() < 2e-3
+    finally:
+        emu_engine.set_option('f16_impl', 'h16')
+        net.init_from_dict(synth_weights, dtype=0)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 17, 21, 128, 256, 0), (2, 14, 20, 64, 128, 1),
                                   # 64-tile x 64-cout items (16-channel steps, swizzled V): conv1_2-like, odd sizes, 3 cout blocks
                                   (2, 16, 32, 64, 64, 1), (1, 17, 21, 32, 64, 0), (1, 12, 20, 96, 192, 0)],

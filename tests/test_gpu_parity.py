@@ -444,6 +444,41 @@ def test_golden_fixtures_gpu(net, synth_weights):
     assert np.abs(o[4][0, ::8, ::8, :] - g['scoremap32']).max() < TOL_HEATMAP
 
 
+def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
+    """conv_h16.hip (the half-precision 3x3 trunk kernel: 1 / 2 / 4 cout blocks per wave, one to three workgroups per CU,
+    pooled and plain epilogues through the LDS slabs) on shapes whose 16 x 16 tiles are ragged at every level (232 x 312 and
+    its pooled sizes), forced onto every eligible layer ("h16_force"), against the f16-rounding oracle and against the general
+    kernel (same MFMA, same packed weights: accumulation order only); the launch counter proves which kernel ran."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net16 = ColorHandPose3DNetwork(engine=gpu_engine)
+    net16.init_from_dict(synth_weights, dtype='f16')
+    try:
+        img = synth.make_batch(510, 3, 232, 312)
+        rs16, _ = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
+        crop = synth.make_batch(110, 2, 256, 256)
+        r16 = N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)
+        out = {}
+        for impl in ('mfma', 'h16_force', 'h16'):
+            gpu_engine.set_option('f16_impl', impl)
+            n0 = gpu_engine.counter('conv_h16_launches')
+            _, small = gpu_engine.handsegnet(img, want_small=True)
+            sms = net16.inference_pose2d(crop)
+            n1 = gpu_engine.counter('conv_h16_launches')
+            out[impl] = (small, sms)
+            assert (n1 - n0 == 0) if impl == 'mfma' else (n1 - n0 >= (13 + 9 if impl == 'h16_force' else 1)), (impl, n1 - n0)
+            assert np.abs(small - rs16).max() < 2e-3
+            for a, b in zip(sms, r16):
+                assert np.abs(a - b).max() < 2e-3
+        for impl in ('h16_force', 'h16'):
+            assert np.abs(out[impl][0] - out['mfma'][0]).max() < 5e-4
+            for a, b in zip(out[impl][1], out['mfma'][1]):
+                assert np.abs(a - b).max() < 5e-4
+    finally:
+        gpu_engine.set_option('f16_impl', 'h16')
+        gpu_engine.load_weight_dict(synth_weights)
+        gpu_engine.finalize_weights(0)
+
+
 def test_f16_trunks_config_c5(gpu_engine, synth_weights):
     """BASELINE config 5 precision: half-precision HandSegNet / PoseNet2D trunks (v_mfma_f32_32x32x16_f16, f32
     accumulate), float32 heads / mask stage / lifting.  Checked against the oracle with the same rounding points

@@ -165,7 +165,21 @@ def main():
     weights = synth.make_weights() if rank == 0 else None
     # native RCCL (hp3d_comm_init + hp3d_bcast_weights) whenever a launcher started us -- also at world size 1, so that a
     # single-GPU box still exercises the exchange
-    sp.sync_weights(weights, dtype=a.dtype, use_comm=launched)
+    comm_mode, comm_err = ('rccl' if launched else 'none'), None
+    try:
+        sp.sync_weights(weights, dtype=a.dtype, use_comm=launched)
+    except Exception as e:                      # RCCL could not be set up on this box
+        if not launched:
+            raise
+        comm_err = '%s: %s' % (type(e).__name__, e)
+    if launched and any(rdzv.allgather(comm_err)):
+        # every rank takes the same degraded path: own copy of the (seeded, identical) weights, gathers over the rendezvous
+        errs = [x for x in rdzv.allgather(comm_err) if x]
+        comm_mode = 'tcp-fallback (%s)' % errs[0][:200]
+        sys.stderr.write('bench.py rank %d: RCCL unavailable, weights loaded per rank and keypoints gathered over TCP: %s\n' % (rank, errs[0]))
+        sp.use_tcp_only()
+        eng.load_weight_dict(synth.make_weights())
+        eng.finalize_weights(a.dtype)
     if a.graph:
         eng.set_option('graph', '1')
     for kv in a.option:
@@ -315,7 +329,7 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                        "parallelism": "batch-shard x%d, one process per GPU, no data-path collective; weights by hp3d_bcast_weights "
                                       "and a per-step keypoint all-gather (RCCL through the C ABI, TCP rendezvous; no torch)" % world,
-                       "hipgraph": bool(a.graph), "options": a.option,
+                       "comm": comm_mode, "hipgraph": bool(a.graph), "options": a.option,
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
             "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu, "epe_vs_oracle": parity,
             "host_path": host_path,

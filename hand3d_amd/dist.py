@@ -187,6 +187,18 @@ class ShardedPipeline(object):
         if self.rdzv is None:
             raise ValueError("world > 1 needs a Rendezvous (Rendezvous.from_env())")
         self.comm_ready = False
+        self.tcp_only = False         # set by use_tcp_only(): gathers travel over the rendezvous sockets, not RCCL
+
+    def use_tcp_only(self):
+        """Degraded mode for a box whose RCCL communicator cannot be built: every rank loads its own weights and the (tiny)
+        per-step keypoint gather travels over the rendezvous' TCP sockets.  Must be entered by ALL ranks."""
+        if self.comm_ready:
+            try:
+                self.engine.comm_destroy()
+            except Exception:
+                pass
+            self.comm_ready = False
+        self.tcp_only = True
 
     def comm_init(self):
         """hp3d_comm_init on every rank: rank 0 draws the 128-byte id, the rendezvous hands it round."""
@@ -213,6 +225,8 @@ class ShardedPipeline(object):
         on the host of every rank (equal shard sizes: the benchmark's weak-scaling layout)."""
         if self.world == 1 and not self.comm_ready:
             return self.engine.to_host(coord_dev, (n_local, 21, 3))
+        if self.tcp_only:
+            return np.concatenate(self.rdzv.allgather(self.engine.to_host(coord_dev, (n_local, 21, 3))), 0)
         return self.engine.allgather_dev(coord_dev, n_local * 63, self.world).reshape(self.world * n_local, 21, 3)
 
     def gather_ragged(self, local_kp, n_total):
@@ -223,6 +237,8 @@ class ShardedPipeline(object):
         pad[:local_kp.shape[0]] = local_kp
         if self.world == 1 and not self.comm_ready:
             return pad[:sizes[0]]
+        if self.tcp_only:
+            return np.concatenate([np.asarray(x)[:s] for x, s in zip(self.rdzv.allgather(pad), sizes)], 0)
         full = self.engine.allgather(pad, self.world).reshape((self.world, mx) + tuple(local_kp.shape[1:]))
         return np.concatenate([full[r, :s] for r, s in enumerate(sizes)], 0)
 

@@ -72,6 +72,10 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            images ("0" = never split; default "auto" = at most 32 in float32 mode -- fewer when H x W x 64 floats x N
  *                            would pass 2^31 bytes, e.g. 480x640: balanced chunks of <= 27 -- and no split with f16 trunks).
  *                            Bit-identical to making the calls chunk by chunk;
+ *          "f16_impl"     = "h16" (default) | "mfma" | "h16_force": with half-precision trunks (hp3d_finalize_weights dtype 1),
+ *                            the 3x3 / stride-1 layers with Cin >= 64 run on the half-precision trunk kernel (conv_h16.hip)
+ *                            whenever their grid fills the chip | never (general kernel only) | whenever the shape allows
+ *                            (tests).  Same MFMA and packed weights either way: results agree to accumulation order;
  *          "graph"        = "0" | "1": the device-pointer entry points (hp3d_infer_full_dev, hp3d_posenet2d_dev) replay
  *                            their launch sequence as one hipGraph from the third identical call on (same shape and
  *                            pointers); meant for small batches.  Default "0".                               */

@@ -49,6 +49,8 @@ class FakeEngine(object):
         return bytes(range(128))
 
     def comm_init(self, rank, world, uid):
+        if os.environ.get('HP3D_FAKE_RCCL_FAIL') == 'all' or os.environ.get('HP3D_FAKE_RCCL_FAIL') == str(rank):
+            raise RuntimeError('ncclCommInitRank: unhandled system error (fake)')
         assert uid == bytes(range(128)), "the rendezvous must deliver rank 0's id unchanged"
         self.rank, self.world = rank, world
         self._rec('comm_init %d/%d' % (rank, world))

@@ -49,6 +49,27 @@ def test_bench_protocol_multi_rank(world):
         assert ('finalize' in log) == (r == 0)
 
 
+@pytest.mark.parametrize('fail', ['all', '1'])
+def test_bench_protocol_rccl_failure_degrades_to_tcp(fail):
+    """If the RCCL communicator cannot be built (on every rank, or on one), ALL ranks switch together: own copy of the seeded
+    weights, per-step gather over the rendezvous sockets; the JSON line still appears and says so."""
+    world, port = 2, _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HP3D_FAKE_RCCL_FAIL=fail)
+        procs.append(subprocess.Popen([sys.executable, HELPER, '--gpus', str(world), '--steps', '2', '--warmup', '1', '--batch', '2',
+                                       '--height', '16', '--width', '16'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    rec = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert rec['n_gpus'] == world and rec['value'] > 0 and rec['config']['comm'].startswith('tcp-fallback')
+    for r, (so, se) in enumerate(outs):
+        log = [l for l in se.splitlines() if l.startswith('FAKELOG')][0]
+        assert log.count('finalize') >= 1 and 'bcast' not in log.split('finalize')[-1]     # every rank ends on its own weights
+
+
 def test_bench_protocol_single_process_plain():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     out = subprocess.run([sys.executable, HELPER, '--steps', '2', '--warmup', '0', '--batch', '2', '--height', '16', '--width', '16',

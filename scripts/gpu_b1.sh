@@ -1,12 +1,13 @@
 #!/bin/bash
-OUT=gpurun_out/b1; mkdir -p $OUT
-for B in 1 4 32; do
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --no-host-path --layers --workload posenet --batch $B > $OUT/pose_b$B.json 2> $OUT/pose_b$B.txt
-python -c "
-import json;d=json.loads(open('$OUT/pose_b$B.json').read().strip().splitlines()[-1]);print('posenet B=$B', d['value'],d['ms_per_step'],d['roofline']['achieved'])"
-done
-for B in 1 8; do
-timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --cpu-seconds 0 --no-host-path --layers --batch $B --height 240 --width 320 > $OUT/full_b$B.json 2> $OUT/full_b$B.txt
-python -c "
-import json;d=json.loads(open('$OUT/full_b$B.json').read().strip().splitlines()[-1]);print('full 240x320 B=$B', d['value'],d['ms_per_step'],d['roofline']['achieved'])"
+# small-batch latency: PoseNet2D B=1 (config 2) and the full path B=1, with and without hipGraph replay
+OUT=gpurun_out/${1:-b1g}; mkdir -p $OUT
+for G in "" "--graph"; do
+  for WL in "posenet 1 256 256" "full 1 240 320" "full 4 240 320"; do
+    set -- $WL
+    timeout 300 python bench.py --gpus 1 --steps 200 --warmup 20 --cpu-seconds 0 --no-host-path --workload $1 --batch $2 --height $3 --width $4 $G > $OUT/b_$1_$2$G.json 2> $OUT/b_$1_$2$G.err
+    python - <<PY
+import json
+r=json.load(open("$OUT/b_$1_$2$G.json")); print("$1 B=$2 graph='$G':", r["value"], "img/s", r["ms_per_step"], "ms", r["config"].get("hipgraph_replays"))
+PY
+  done
 done

@@ -59,10 +59,26 @@ def main():
         hit = '%.2f' % (sum(x[0] * x[3] for x in hv) / sum(x[0] for x in hv)) if hv else '-'
         lines.append('| %s | %d | %.0f..%.0f | %.2f | %.3f | %.3f | %s |' % (k.replace('conv_h16_kernel', ''), len(v), min(x[0] for x in v), max(x[0] for x in v),
                                                                       clock, busy, busy * clock / 2.4, hit))
-    lines += ['', 'Reading: the matrix pipe is busy 0.5-0.65 of the time, and the chip runs these kernels at 1.5-1.75 GHz (it clocks to its',
+    lines += ['', 'Reading: the matrix pipe is busy 0.5-0.73 of the time, and the chip runs these kernels at 1.5-1.7 GHz (it clocks to its',
               'power budget; profiled passes run a little lower than unprofiled ones), so busy x clock / 2.4 GHz -- the fraction of the',
-              '2.5 PF dense f16 peak the MFMAs executed -- comes to 0.35-0.45, which is what bench.py reports from its own event timing.',
+              '2.5 PF dense f16 peak the MFMAs executed -- comes to 0.36-0.48, which is what bench.py reports from its own event timing.',
               'Raising `MFMA busy` returns only partly as throughput (denser bodies clock lower: MI355X_MICROARCH.md, DVFS give-back).']
+    # kernel families of the same run (kernel trace of the first SQ pass: one warm-up + one timed step, B=32 480x640, f16 trunks)
+    kt = os.path.join(src, 'SQ_INSTS_VALU_MFMA_MOPS_F16_SQ_BUSY_CYCLES', 'hp3d_kernel_trace.csv')
+    if os.path.exists(kt):
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from summarize_prof import family
+        fam = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(kt)):
+            f = fam[family(r['Kernel_Name'])]
+            f[0] += 1
+            f[1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6
+        tot = sum(v[1] for v in fam.values())
+        lines += ['', '## Kernel families of the same command (rocprofv3 --kernel-trace of the counter pass; half-precision trunks, B=32, 480x640)', '',
+                  '| kernel family | launches | total ms | avg launch us | % GPU time |', '|---|---|---|---|---|']
+        for k, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+            if ms / tot > 0.002:
+                lines.append('| %s | %d | %.2f | %.1f | %.1f |' % (k, n, ms, ms / n * 1e3, 100 * ms / tot))
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', tag + '_h16_counters.md')
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))

@@ -18,8 +18,9 @@
 //     the same speed as this form -- the store form is not the limiter.  A pure fill kernel reaches 5.1-5.8 TB/s on this
 //     GPU (scripts/micro/write_bw.hip); this kernel writes at 3.6 TB/s next to its gathers and 28 MFMAs per tile;
 //   * no LDS, ~100 registers: four waves per SIMD hide the rest; a workgroup walks a strip of tiles;
-//   * F16 = true (half-precision trunks, BASELINE config 5): operands rounded to half (what the f16 MFMA of the general kernel
-//     multiplies), float32 accumulate, and the 32 x 64 block leaves as HALVES: 2-byte stores would be issue-bound, so the wave's
+//   * F16 = true (half-precision trunks, BASELINE config 5): operands rounded to half and multiplied by v_mfma_f32_32x32x16_f16
+//     (K = 27 + two bias rows in two K = 16 steps: 4 MFMAs of 32 cycles per 32 x 64 block instead of 28 of 64 -- the f32
+//     form was matrix-bound at half-precision store rates), float32 accumulate, and the 32 x 64 block leaves as HALVES: 2-byte stores would be issue-bound, so the wave's
 //     block is transposed through a private 4.5 KB LDS slab (ds_write_b64 from the D[cout][pixel] register layout, where
 //     registers 4a..4a+3 are four consecutive couts of a pixel) into 16-byte stores in which 8 consecutive lanes write the
 //     whole 128-byte row of a pixel (config 5, 480x640 B=128: 4.5 ms on the general kernel -> see profiles/r02_tuning_notes.md).
@@ -36,21 +37,41 @@ template <bool F16>
 HP3D_KERNEL(256)
 void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
     HP3D_DYN_SMEM(slab_all);
-    auto rnd = [](float v) { return F16 ? (float)(hp3d_f16)v : v; };
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int m = lane & 31, kh = lane >> 5;
     // filter operands: k = 2 kk + kh, engine channel e = k = (r*3+s)*3 + c of the packed K=32 x 64 matrix
     // wpk[c8][co32][h][n][j] (engine.hip:pack_conv, mode 1)
+    // F16: v_mfma_f32_32x32x16_f16, K = 32 in two steps; operand slot q = 8 j + i of step j is k = 16 j + 8 kh + i.  The bias
+    // rides in TWO spare rows as hi + lo halves (k = 27, 28; image operand 1.0): float32 bias to 2^-22
+    constexpr int NK = F16 ? 16 : FK;
+    auto kof = [&](int q) { return F16 ? 16 * (q >> 3) + 8 * kh + (q & 7) : 2 * q + kh; };
+    auto wat = [&](int nb, int k) { return p.wpk[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)]; };
     float bw[2][FK];
+    f32x4 bwh[2][2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
+    for (int nb = 0; nb < 2; ++nb) {
+        if (F16) {
+            const float bias = p.bias[nb * 32 + m], bias_hi = (float)(hp3d_f16)bias;
 #pragma unroll
-        for (int kk = 0; kk < FK; ++kk) {
-            const int k = 2 * kk + kh;
-            bw[nb][kk] = k == 27 ? p.bias[nb * 32 + m]        // the spare K row carries the bias (its image operand is 1)
-                                 : rnd(p.wpk[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)]);
+            for (int j = 0; j < 2; ++j) {
+                f16x8 h;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * j + 8 * kh + i;
+                    h[i] = (hp3d_f16)(k < 27 ? wat(nb, k) : k == 27 ? bias_hi : k == 28 ? bias - bias_hi : 0.f);
+                }
+                bwh[nb][j] = __builtin_bit_cast(f32x4, h);
+            }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < FK; ++kk) {
+                const int k = 2 * kk + kh;
+                bw[nb][kk] = k == 27 ? p.bias[nb * 32 + m]    // the spare K row carries the bias (its image operand is 1)
+                                     : wat(nb, k);
+            }
         }
+    }
 
     const int strips = (p.tiles_x + tiles_per_wg - 1) / tiles_per_wg;
     int sp = blockIdx.x;
@@ -65,23 +86,20 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
 
     // image operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
     const int y = ty * FT_TH + 2 * wave + (m >> 4);
-    auto gather = [&](int tx, float (&a)[FK]) {
+    auto gather = [&](int tx, float (&a)[NK]) {
         const int x = tx * FT_TW + (m & 15);
 #pragma unroll
-        for (int kk = 0; kk < FK; ++kk) {
-            const int k = 2 * kk + kh;
+        for (int q = 0; q < NK; ++q) {
+            const int k = kof(q);
             const int r = k / 9, s = (k / 3) % 3, c = k % 3;
             const int yy = y + r - 1, xx = x + s - 1;
             const bool ok = k < 27 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-            a[kk] = HP3D_BUFFER_LOAD4(irsrc, ok ? (((b * p.H + yy) * p.W + xx) * 3 + c) * 4 : OOR, 0);
+            a[q] = HP3D_BUFFER_LOAD4(irsrc, ok ? (((b * p.H + yy) * p.W + xx) * 3 + c) * 4 : OOR, 0);
         }
-        if (F16) {
-#pragma unroll
-            for (int kk = 0; kk < FK; ++kk) a[kk] = rnd(a[kk]);
-        }
-        if (kh) a[FK - 1] = 1.0f;              // k = 27: multiplies the bias row
+        if (F16) { if (kh) a[11] = a[12] = 1.0f; }       // k = 27, 28: multiply the two bias rows
+        else if (kh) a[FK - 1] = 1.0f;                    // k = 27: multiplies the bias row
     };
-    float a_cur[FK], a_nxt[FK];
+    float a_cur[NK], a_nxt[NK];
     gather(tx0, a_cur);
     for (int tx = tx0; tx < tx1; ++tx) {
         if (tx + 1 < tx1) gather(tx + 1, a_nxt);
@@ -89,13 +107,18 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (F16) {
             // D[cout][pixel]: this lane holds pixel m; accumulator register 4a + j of half nb is cout 32 nb + 8 a + 4 kh + j
-            acc0 = HP3D_MFMA_32x32x2(bw[0][0], a_cur[0], zero);
-            acc1 = HP3D_MFMA_32x32x2(bw[1][0], a_cur[0], zero);
+            f32x4 ah[2];
 #pragma unroll
-            for (int kk = 1; kk < FK; ++kk) {
-                acc0 = HP3D_MFMA_32x32x2(bw[0][kk], a_cur[kk], acc0);
-                acc1 = HP3D_MFMA_32x32x2(bw[1][kk], a_cur[kk], acc1);
+            for (int j = 0; j < 2; ++j) {
+                f16x8 h;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) h[i] = (hp3d_f16)a_cur[8 * j + i];
+                ah[j] = __builtin_bit_cast(f32x4, h);
             }
+            acc0 = HP3D_MFMA_32x32x16_F16(bwh[0][0], ah[0], zero);
+            acc1 = HP3D_MFMA_32x32x16_F16(bwh[1][0], ah[0], zero);
+            acc0 = HP3D_MFMA_32x32x16_F16(bwh[0][1], ah[1], acc0);
+            acc1 = HP3D_MFMA_32x32x16_F16(bwh[1][1], ah[1], acc1);
             hp3d_f16* slab = (hp3d_f16*)slab_all + wave * (32 * FT_PITCH_H);
             HP3D_WAVE_LDS_SYNC();                 // the previous tile's slab reads are done
 #pragma unroll
@@ -140,7 +163,7 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < FK; ++kk) a_cur[kk] = a_nxt[kk];
+        for (int q = 0; q < NK; ++q) a_cur[q] = a_nxt[q];
     }
 }
 

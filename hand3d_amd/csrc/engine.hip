@@ -492,7 +492,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         conv_first_launch(p, ctx->stream);
     } else if (f16 && ctx->use_h16 && l.mode == 0 && !ctx->conv_naive &&
                conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32, out_cs) &&
-               ((uintptr_t)out & 15) == 0) {
+               ((uintptr_t)out & 15) == 0 && !(pool && ((Ho | Wo) & 1))) {
         ConvParams p;
         p.in = in; p.wpk = (const float*)(ctx->blob16 + l.w16_off); p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;

@@ -52,10 +52,16 @@ constexpr int HRING = HP3D_H16_RING;                  // K-steps of weight fragm
 // WPS = workgroups per CU (waves per SIMD).  WPS == 1: the patch is double buffered (the next chunk streams in under the
 // current one).  WPS > 1 (NT <= 2: few accumulators, few chunks, store-heavy): ONE patch buffer, and the load / store phases
 // of one workgroup are covered by the MFMAs of the other(s) on the same CU.
-template <int NT, bool POOL, int WPS>
+// FUSE (NT = 1, POOL: the first block of both trunks, nets/ColorHandPose3DNetwork.py:144-145,183-184): `in` is the raw
+// float32 image and the 18 x 18 x 64 patch of conv1_1's output is COMPUTED into LDS instead of loaded -- 11 row blocks of 32
+// patch pixels, K = 27 + two bias rows in two v_mfma_f32_32x32x16_f16 steps with the operand order, rounding points and
+// accumulation order of conv_first_kernel<true> (bit-identical halves), leaky-ReLU, zero outside the image (conv1_2's
+// SAME padding pads conv1_1's OUTPUT) -- so that conv1_1's 64-channel activation (5 GB at 128 x 480 x 640) never goes to HBM.
+template <int NT, bool POOL, int WPS, bool FUSE = false>
 HP3D_KERNEL2(256, WPS)
 void conv_h16_kernel(const ConvParams p) {
     constexpr bool DB = WPS == 1;
+    static_assert(!FUSE || (NT == 1 && POOL && !DB), "fused first block: 64 -> 64 couts, pooled, single patch buffer");
     HP3D_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
@@ -70,14 +76,54 @@ void conv_h16_kernel(const ConvParams p) {
     const int nitems = p.B * tiles_y * tiles_x * ncb;
     const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
 
-    // A fragment rows of this lane: M-block mt of pixel half wm covers output rows 8 wm + 2 mt, +1 (32 pixels = 2 rows x 16);
-    // MFMA row r -> quad r >> 2, (dy, dx) = ((r >> 1) & 1, r & 1): four accumulator registers = one 2x2 pooling window
+    // A fragment rows of this lane: M-block mt of pixel half wm covers output rows 8 wm + 2 mt, +1 (32 pixels = 2 rows x 16).
+    // MFMA column li -> pixel (dy, x) of the block.  ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS table) -- and a group is conflict-free when its 16
+    // lanes' 16-byte pieces fall into 16 different 4-bank columns: with the 144-byte pixel pitch that is "16 different patch
+    // pixel indices mod 16".  Rows are 18 pixels apart, so the lanes of a group take x = 0..7 of row 0 with x = 6..13 of row 1,
+    // or x = 8..15 of row 0 with x = 14, 15, 0..5 of row 1 (a plain 16-lanes-per-row map would be 2-way conflicted: 8 LDS
+    // cycles per read instead of 4).  Tap and K-step offsets shift all lanes alike and keep the property.
+    const int pdy = li >> 4;
+    const int pj = li & 15;
+    const int pdx = pdy == 0 ? (pj < 4 ? pj : pj < 12 ? pj + 4 : pj - 8)
+                             : (pj < 2 ? pj + 14 : pj < 4 ? pj - 2 : pj < 12 ? pj + 2 : pj - 10);
     int abase[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        const int q = li >> 2, dx = li & 1, dy = (li >> 1) & 1;
-        const int ly = (wm * 4 + mt) * 2 + dy, lx = 2 * q + dx;
-        abase[mt] = ((ly * HPW + lx) * HPITCH + lh * 4) * 4;          // bytes
+        const int ly = (wm * 4 + mt) * 2 + pdy;
+        abase[mt] = ((ly * HPW + pdx) * HPITCH + lh * 4) * 4;         // bytes
+    }
+    // fused first block: conv1_1's 32 x 64 filter matrix (K slot q = 8 j + i of step j is k = 16 j + 8 kh + i; k = (r*3+s)*3+c;
+    // k = 27, 28 carry the float32 bias as hi + lo halves) in 16 registers for the whole kernel, as in conv_first.hip
+    f32x4 bwh[2][2];
+    if (FUSE) {
+        const int m = li, kh = lh;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float bias = p.bias1[nb * 32 + m], bias_hi = (float)(hp3d_f16)bias;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x8 hh;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * j + 8 * kh + i;
+                    const float wv = k < 27 ? p.wpk1[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)] : 0.f;
+                    hh[i] = (hp3d_f16)(k < 27 ? wv : k == 27 ? bias_hi : k == 28 ? bias - bias_hi : 0.f);
+                }
+                bwh[nb][j] = __builtin_bit_cast(f32x4, hh);
+            }
+        }
+    }
+    // ... and where operand slot q sits in the staged image window relative to the pixel's (row - 1, col - 1) corner; the two
+    // bias rows read the constant 1.0 and the K tail the constant 0.0 parked behind the window (negative = absolute index)
+    int fkoff[16];
+    if (FUSE) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = 16 * (q >> 3) + 8 * lh + (q & 7);
+            const int r = k / 9, sx = (k / 3) % 3, c = k % 3;
+            fkoff[q] = k < 27 ? (r * (HPW + 2) + sx) * 3 + c : k < 29 ? -((HPW + 2) * (HPW + 2) * 3) : -((HPW + 2) * (HPW + 2) * 3 + 1);
+        }
     }
     const int wbase = (tid >> 3) * HPITCH + (tid & 7) * 4;     // LDS float index of this thread's patch piece 0 (piece v: + 32 v pixels)
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(9 * p.Cin) * (unsigned)p.Cout * 4u);
@@ -94,7 +140,8 @@ void conv_h16_kernel(const ConvParams p) {
         // the image edge and idx past the patch get an out-of-range offset, which a buffer load answers with zeros.
         // Pieces move in HPG groups of HPGS (fetch -> registers -> LDS) so that only HPGS x 4 registers hold patch data.
         constexpr int OOR = (int)0x80000000;
-        const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in + (size_t)b * p.H * p.W * p.in_cs, (unsigned)(p.H * p.W) * (unsigned)p.in_cs * 4u);
+        const hp3d_rsrc_t irsrc = FUSE ? HP3D_MAKE_RSRC(p.in + (size_t)b * p.H * p.W * 3, (unsigned)(p.H * p.W) * 12u)
+                                       : HP3D_MAKE_RSRC(p.in + (size_t)b * p.H * p.W * p.in_cs, (unsigned)(p.H * p.W) * (unsigned)p.in_cs * 4u);
         int poff[HPVEC];
 #pragma unroll
         for (int v = 0; v < HPVEC; ++v) {
@@ -154,8 +201,64 @@ void conv_h16_kernel(const ConvParams p) {
             for (int v = 0; v < HPVEC; ++v)
                 if (tid + v * 256 < HPIECES) *(f32x4*)(smem + wbase + v * (32 * HPITCH)) = first[v];
         };
+        // fused first block: the patch = conv1_1 over the image.  The 20 x 20 x 3 float32 image window (zero outside the image)
+        // is staged in LDS behind the patch buffer, followed by the constants 1.0 (bias rows) and 0.0 (K tail); then, row block by
+        // row block of 32 patch pixels (wave w: blocks w, w + 4, w + 8), lane (pixel, K half) reads its 16 operands at
+        // window[pixel base + fkoff[q]] -- fkoff = (r * 20 + s) * 3 + c of k = (r*3+s)*3+c, set once per kernel
+        constexpr int FWIN = (HPW + 2) * (HPW + 2) * 3;          // 1200 floats
+        float* fwin = smem + HPATCH_FLOATS;
+        auto build_patch = [&]() {
+#pragma unroll
+            for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, s & 3);
+#pragma unroll
+            for (int v = 0; v < (FWIN + 2 + 255) / 256; ++v) {
+                const int f = tid + v * 256;
+                const int row = f / ((HPW + 2) * 3), rem = f - row * ((HPW + 2) * 3), col = rem / 3, c = rem - col * 3;
+                const int yy = oy0 - 2 + row, xx = ox0 - 2 + col;
+                const bool ok = f < FWIN && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+                const float val = HP3D_BUFFER_LOAD4(irsrc, ok ? ((yy * p.W + xx) * 3 + c) * 4 : OOR, 0);
+                if (f < FWIN + 2) fwin[f] = f == FWIN ? 1.0f : val;           // [FWIN] = 1.0, [FWIN + 1] = 0.0
+            }
+            __syncthreads();
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int blk = wave; blk < (HPW * HPW + 31) / 32; blk += 4) {
+                const int pp = blk * 32 + li;                  // patch pixel of this lane
+                const int ppc = pp < HPW * HPW ? pp : 0;
+                const int py = ppc / HPW, px = ppc - py * HPW;
+                const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;               // conv1_1 output position
+                const bool inside = pp < HPW * HPW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+                const float* wb = fwin + (py * (HPW + 2) + px) * 3;           // window row py-1+1.., i.e. image (gy - 1, gx - 1)
+                f32x4 ah[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f16x8 hh;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) hh[i] = (hp3d_f16)(fkoff[8 * j + i] >= 0 ? wb[fkoff[8 * j + i]] : fwin[-fkoff[8 * j + i]]);
+                    ah[j] = __builtin_bit_cast(f32x4, hh);
+                }
+                f32x16 c0 = HP3D_MFMA_32x32x16_F16(bwh[0][0], ah[0], zero);
+                f32x16 c1 = HP3D_MFMA_32x32x16_F16(bwh[1][0], ah[0], zero);
+                c0 = HP3D_MFMA_32x32x16_F16(bwh[0][1], ah[1], c0);
+                c1 = HP3D_MFMA_32x32x16_F16(bwh[1][1], ah[1], c1);
+                // register 4a + e of half nb = cout 32 nb + 8 a + 4 lh + e of pixel pp: 8-byte pieces of the 144-byte patch row
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f16x4 h0, h1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v0 = c0[4 * a + e], v1 = c1[4 * a + e];
+                        v0 = fmaxf(v0, HP3D_LEAKY_SLOPE * v0); v1 = fmaxf(v1, HP3D_LEAKY_SLOPE * v1);
+                        h0[e] = inside ? (hp3d_f16)v0 : (hp3d_f16)0.f; h1[e] = inside ? (hp3d_f16)v1 : (hp3d_f16)0.f;
+                    }
+                    if (pp < HPW * HPW) {
+                        *(f16x4*)((char*)smem + pp * (HPITCH * 4) + (8 * a + 4 * lh) * 2) = h0;
+                        *(f16x4*)((char*)smem + pp * (HPITCH * 4) + (32 + 8 * a + 4 * lh) * 2) = h1;
+                    }
+                }
+            }
+        };
         __syncthreads();                       // the previous item's waves are done with the patch buffers / slabs
-        load_chunk(0);
+        if constexpr (FUSE) build_patch(); else load_chunk(0);
         __syncthreads();
         int cur = 0;
         for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -226,8 +329,8 @@ void conv_h16_kernel(const ConvParams p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a)
                 bias4[nt][a] = *(const f32x4*)(p.bias + cb * BN + (wn * NT + nt) * 32 + a * 8 + lh * 4);
-        // slab pixel of MFMA column li (the 2x2 quad order of abase): sp = 16 dy + 2 q + dx
-        const int sp_w = ((li >> 1) & 1) * 16 + 2 * (li >> 2) + (li & 1);
+        // slab pixel of MFMA column li (the lane -> pixel map of abase): sp = 16 dy + x
+        const int sp_w = pdy * 16 + pdx;
         const int wr_off = sp_w * SPITCH + lh * 8;
         const int g = lane % G, sp0 = lane / G;                              // read side: lane -> (pixel sp0 + k PPR, group g)
         const int cbyte = (cb * BN + wn * (32 * NT)) * 2 + g * 16;
@@ -314,7 +417,30 @@ inline int h16_nt(int Cout, int cin_units) {
     return nt < HP3D_H16_MAXNT ? nt : HP3D_H16_MAXNT;
 }
 
+void h16_fused12_launch_t(const ConvParams& p, hipStream_t s) {
+    static bool attr_done[64] = {};
+#ifndef HP3D_H16_FWPS
+#define HP3D_H16_FWPS 2
+#endif
+    constexpr int WPS = HP3D_H16_FWPS;
+    auto k = conv_h16_kernel<1, true, WPS, true>;
+    constexpr int SLABS = 4 * 4 * 32 * (64 + 16);
+    constexpr int PATCH = HPATCH_FLOATS * 4 + ((HPW + 2) * (HPW + 2) * 3 + 2 + 2) * 4;       // patch + staged image window + constants
+    constexpr int SMEM = PATCH > SLABS ? PATCH : SLABS;
+    if (hp3d_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    const long items = (long)p.B * ((p.Ho + HT - 1) / HT) * ((p.Wo + HT - 1) / HT);
+    const int slots = hp3d_num_cus() * WPS;
+    HP3D_LAUNCH(k, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SMEM, s, p);
+}
+
 }  // namespace
+
+int conv_h16_fused12_launch(const ConvParams& p, hipStream_t s) {
+    if (p.Cout != 64 || p.Cin != 32 || !p.wpk1 || !p.bias1 || ((p.Ho | p.Wo) & 1) || !p.act) return -1;
+    h16_fused12_launch_t(p, s);
+    return 0;
+}
 
 // 3x3 / stride 1, half-precision operands and output (not the float32 score-map heads), Cin a multiple of 64 halves,
 // Cout a multiple of 64, output pixel stride a multiple of 8 halves (16-byte stores); enough work items to fill the chip.

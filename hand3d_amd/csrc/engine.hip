@@ -254,6 +254,7 @@ struct hp3d_ctx {
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
+    int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12")
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
@@ -550,6 +551,30 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
 const ConvL& CL(hp3d_ctx* ctx, const char* name) { return ctx->T.conv[ctx->T.conv_idx.at(name)]; }
 const FcL& FL(hp3d_ctx* ctx, const char* name) { return ctx->T.fc[ctx->T.fc_idx.at(name)]; }
 
+// Half-precision trunks: conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool as ONE launch of conv_h16.hip's fused form
+// (conv1_1's activation never reaches HBM).  Returns 1 if it ran, 0 if the shape / options do not allow it.
+int run_fused12(hp3d_ctx* ctx, const ConvL& l1, const ConvL& l2, const float* image, int B, int H, int W, float* out, int* oh, int* ow) {
+    if (!ctx->prec || !ctx->use_h16 || !ctx->fuse12 || ctx->conv_naive || l1.mode != 1 || l2.mode != 0 || l1.cout != 64 || l2.cout != 64 ||
+        !l1.relu || !l2.relu || ((H | W) & 1) || ((uintptr_t)out & 15) ||
+        !conv_h16_eligible(ctx->use_h16, l2.k, l2.stride, l2.cin_pad16 / 2, l2.cout_pad, H, W, B, 0, 64))
+        return 0;
+    ConvParams p;
+    p.in = image; p.wpk = (const float*)(ctx->blob16 + l2.w16_off); p.bias = ctx->blob + l2.b_off; p.out = out;
+    p.wpk1 = ctx->blob + l1.w_off; p.bias1 = ctx->blob + l1.b_off;
+    p.B = B; p.H = H; p.W = W; p.Ho = H; p.Wo = W;
+    p.Cin = l2.cin_pad16 / 2; p.in_cs = 3; p.Cout = 64; p.out_cs = 64; p.cout_store = 64;
+    p.pad_t = 1; p.pad_l = 1; p.tiles_x = 0; p.tiles_y = 0;
+    p.act = 1; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = 1; p.out_f32 = 0; p.nsub = 1;
+    const double px = (double)B * H * W;
+    const double flops = 2.0 * 9 * (3.0 * 64 + 64.0 * 64) * px;
+    const double bytes = px * 12 + 2.0 * (9 * 3 * 64 + 9 * 64 * 64) + 2.0 * px / 4 * 64;
+    ProfScope ps(ctx, l2.name, "conv_h16_fused_c1_1+c1_2_pool", flops, bytes);
+    ++ctx->conv_h16_launches;
+    if (conv_h16_fused12_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 fused launch failed for %s", l2.name.c_str());
+    *oh = H / 2; *ow = W / 2;
+    return 1;
+}
+
 // VGG-style trunk shared by HandSegNet and PoseNet2D: conv1_1 (im2col) ... through block 4's first
 // `n4` layers.  Returns the activation pointer / size after the trunk.
 int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H, int W, int n4, float** act, int* h,
@@ -560,10 +585,16 @@ int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H
     const int f16 = ctx->prec;        // activations below are halves when set (same buffers, half the bytes)
     int ch = 64, ih = H, iw = W;
     snprintf(nm, sizeof nm, "%s/conv1_1", scope);
-    CHK(run_conv(ctx, CL(ctx, nm), image, 3, B, ih, iw, a, 64, 0, nullptr, nullptr, f16));   // im2col fused in the loader
+    char nm2[64];
+    snprintf(nm2, sizeof nm2, "%s/conv1_2", scope);
+    int first = 1, fh = 0, fw = 0;
+    const int fused = f16 ? run_fused12(ctx, CL(ctx, nm), CL(ctx, nm2), image, B, ih, iw, a, &fh, &fw) : 0;
+    if (fused < 0) return fused;
+    if (fused) { first = 2; ih = fh; iw = fw; }
+    else CHK(run_conv(ctx, CL(ctx, nm), image, 3, B, ih, iw, a, 64, 0, nullptr, nullptr, f16));   // im2col fused in the loader
     const int nl[4] = {2, 2, 4, n4}, chs[4] = {64, 128, 256, 512};
     for (int blk = 0; blk < 4; ++blk) {
-        for (int i = (blk == 0 ? 1 : 0); i < nl[blk]; ++i) {
+        for (int i = (blk == 0 ? first : 0); i < nl[blk]; ++i) {
             snprintf(nm, sizeof nm, "%s/conv%d_%d", scope, blk + 1, i + 1);
             const int pool = (blk < 3 && i == nl[blk] - 1) ? 1 : 0;
             int oh, ow;
@@ -884,7 +915,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_h16 = ctx->use_h16; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1195,6 +1226,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
     if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {

@@ -126,6 +126,10 @@ struct ConvParams {
     int out_f32;          // f16 mode only: store float32 (score-map heads) instead of halves
     int im2col;           // 1: `in` is a raw [B,H,W,3] image, the A tile is built as a 3x3 im2col row (conv1_1)
     int nsub;             // conv_wino: 1 = 3x3 filter; 9 = 7x7 filter as 3x3 blocks of its zero-extended 9x9 form
+    // conv_h16 fused first block (conv1_1 -> conv1_2 + pool): `in` is the raw [B,H,W,3] float32 image and these are conv1_1's
+    // packed weights (mode 1, as conv_first reads them) and bias; nullptr otherwise
+    const float* wpk1 = nullptr;
+    const float* bias1 = nullptr;
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------
@@ -146,6 +150,8 @@ void wino_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pa
 // half-precision 3x3 trunk layers on their own kernel (conv_h16.hip): returns per-wave cout blocks (1, 2, 4) or 0
 int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32, int out_cs);
 int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s);
+// conv1_1 (3 -> 64) computed per patch inside conv1_2 (64 -> 64, pooled): p.in = image, p.wpk1 / p.bias1 = conv1_1
+int conv_h16_fused12_launch(const ConvParams& p, hipStream_t s);
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16);
 int conv_first_launch(const ConvParams& p, hipStream_t s);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,

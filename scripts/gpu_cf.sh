@@ -3,5 +3,5 @@ for S in "32 480 640" "128 480 640"; do set -- $S
 timeout 300 python bench.py --gpus 1 --steps 4 --warmup 1 --layers --cpu-seconds 0 --no-host-path --option streams=1 --dtype f16 --batch $1 --height $2 --width $3 > gpurun_out/cf_$1.json 2> gpurun_out/cf_$1.txt
 python -c "
 import json; r=json.load(open('gpurun_out/cf_$1.json')); print('B=$1', r['value'], 'img/s', r['ms_per_step'])"
-grep -E "conv1_1|conv1_2 " gpurun_out/cf_$1.txt
+grep -E "conv1_1|conv1_2 |conv2_1 " gpurun_out/cf_$1.txt
 done

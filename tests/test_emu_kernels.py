@@ -189,11 +189,17 @@ def test_f16_trunks_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights)
             rs, _ = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
             assert np.abs(small - rs).max() < 2e-3
             assert np.abs(small - small_ref).max() < 5e-4
+            # conv1_1 computed inside conv1_2's patch stage (the default) == the two-launch form, bit for bit
+            emu_engine.set_option('f16_fuse12', '0')
+            _, small_unfused = emu_engine.handsegnet(img, want_small=True)
+            emu_engine.set_option('f16_fuse12', '1')
+            assert np.array_equal(small, small_unfused)
         crop = synth.make_batch(9, 1, 16, 16)
         for a, b in zip(net.inference_pose2d(crop), N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)):
             assert np.abs(a - b).max() < 2e-3
     finally:
         emu_engine.set_option('f16_impl', 'h16')
+        emu_engine.set_option('f16_fuse12', '1')
         net.init_from_dict(synth_weights, dtype=0)
 
 

@@ -473,7 +473,17 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
             assert np.abs(out[impl][0] - out['mfma'][0]).max() < 5e-4
             for a, b in zip(out[impl][1], out['mfma'][1]):
                 assert np.abs(a - b).max() < 5e-4
+        # conv1_1 computed inside conv1_2's patch stage (default) == conv_first<F16> followed by conv_h16, bit for bit
+        gpu_engine.set_option('f16_impl', 'h16_force')
+        gpu_engine.set_option('f16_fuse12', '0')
+        _, small_unfused = gpu_engine.handsegnet(img, want_small=True)
+        sms_unfused = net16.inference_pose2d(crop)
+        gpu_engine.set_option('f16_fuse12', '1')
+        assert np.array_equal(out['h16_force'][0], small_unfused)
+        for a, b in zip(out['h16_force'][1], sms_unfused):
+            assert np.array_equal(a, b)
     finally:
+        gpu_engine.set_option('f16_fuse12', '1')
         gpu_engine.set_option('f16_impl', 'h16')
         gpu_engine.load_weight_dict(synth_weights)
         gpu_engine.finalize_weights(0)

@@ -47,7 +47,15 @@ constexpr int HPSTEP = 36 / HPG;         // K-steps between the fetches of succe
 #ifndef HP3D_H16_RING
 #define HP3D_H16_RING 6
 #endif
-constexpr int HRING = HP3D_H16_RING;                  // K-steps of weight fragments in flight per wave
+#ifndef HP3D_H16_RING2
+#define HP3D_H16_RING2 6
+#endif
+#ifndef HP3D_H16_RING1
+#define HP3D_H16_RING1 6
+#endif
+// K-steps of weight fragments in flight per wave, by cout blocks per wave NT (a step is 4 NT MFMAs x 32 cycles: the fewer
+// blocks, the shorter the time a ring of a given depth covers)
+constexpr int h16_ring(int nt) { return nt == 4 ? HP3D_H16_RING : nt == 2 ? HP3D_H16_RING2 : HP3D_H16_RING1; }
 
 // WPS = workgroups per CU (waves per SIMD).  WPS == 1: the patch is double buffered (the next chunk streams in under the
 // current one).  WPS > 1 (NT <= 2: few accumulators, few chunks, store-heavy): ONE patch buffer, and the load / store phases
@@ -61,6 +69,7 @@ template <int NT, bool POOL, int WPS, bool FUSE = false>
 HP3D_KERNEL2(256, WPS)
 void conv_h16_kernel(const ConvParams p) {
     constexpr bool DB = WPS == 1;
+    constexpr int HRING = h16_ring(NT);
     static_assert(!FUSE || (NT == 1 && POOL && !DB), "fused first block: 64 -> 64 couts, pooled, single patch buffer");
     HP3D_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;

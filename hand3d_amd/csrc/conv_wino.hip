@@ -436,7 +436,7 @@ int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, i
     int ks = (int)((256 + items - 1) / items);
     if (ks > nsteps / 2) ks = nsteps / 2;
     if (ks > 16) ks = 16;
-    if (!pool && ks >= 2 && ksplit && (long)ks * B * Ho * Wo * Cout * 4 < (1L << 31) && (mode == 2 || items * ks >= 96)) {
+    if (ks >= 2 && ksplit && !(pool && ((Ho | Wo) & 1)) && (long)ks * B * Ho * Wo * Cout * 4 < (1L << 31) && (mode == 2 || items * ks >= 96)) {
         *ksplit = ks;
         return nt;
     }

@@ -473,13 +473,18 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         }
         {
             ProfScope ps(ctx, l.name, l.k == 7 ? (wino_ks > 1 ? "conv_wino_f2x2_3x3_as7x7_splitk" : "conv_wino_f2x2_3x3_as7x7")
-                                      : pool ? "conv_wino_f2x2_3x3_pool" : wino_ks > 1 ? "conv_wino_f2x2_3x3_splitk" : "conv_wino_f2x2_3x3", flops, bytes);
-            if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+                                      : wino_ks > 1 ? "conv_wino_f2x2_3x3_splitk" : pool ? "conv_wino_f2x2_3x3_pool" : "conv_wino_f2x2_3x3", flops, bytes);
+            // split channel steps: raw partial sums at conv resolution, the pool (if any) happens in the reduce
+            if (conv_wino_launch(p, wino_ks > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
         }
         if (wino_ks > 1) {
-            ProfScope ps(ctx, l.name, "conv_splitk_reduce", 0.0, 4.0 * (wino_ks + 1) * B * Ho * Wo * l.cout_pad);
-            conv_splitk_reduce_launch(ctx->col, wino_ks, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
-                                      std::min(l.cout_pad, out_cs), ctx->stream);
+            ProfScope ps(ctx, l.name, pool ? "conv_splitk_reduce_pool" : "conv_splitk_reduce", 0.0, 4.0 * (wino_ks + 1) * B * Ho * Wo * l.cout_pad);
+            if (pool)
+                conv_splitk_reduce_pool_launch(ctx->col, wino_ks, B, Ho, Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                               std::min(l.cout_pad, out_cs), ctx->stream);
+            else
+                conv_splitk_reduce_launch(ctx->col, wino_ks, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                          std::min(l.cout_pad, out_cs), ctx->stream);
         }
     } else if (l.mode == 1 && !pool && !out_f32 && ctx->use_first && !ctx->conv_naive &&
                conv_first_eligible(l.k, l.stride, l.cin, l.cout, B, H, W, out_cs, f16)) {
@@ -1660,8 +1665,10 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
             d_part = S.alloc<float>((size_t)op_ks * B * Ho * Wo * Cout); NN(ctx, d_part);
             p.out = d_part;
         }
-        if (conv_wino_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
-        if (op_ks > 1)
+        if (conv_wino_launch(p, op_ks > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv: tensor exceeds 32-bit offsets");
+        if (op_ks > 1 && pool)
+            conv_splitk_reduce_pool_launch(d_part, op_ks, B, Ho, Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
+        else if (op_ks > 1)
             conv_splitk_reduce_launch(d_part, op_ks, (long)B * Ho * Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
     } else if (ctx->conv_naive) {
         if (pool) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "naive conv has no fused pool");

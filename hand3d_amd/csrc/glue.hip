@@ -56,6 +56,34 @@ void conv_splitk_reduce_kernel(const float* partial, int ksplit, long npix, int 
     }
 }
 
+// the same followed by the 2x2 / 2 max-pool of the layer (NetworkOps.max_pool, utils/general.py:61-65): partial sums are
+// [ksplit][B, H, W][Cout] at conv resolution, the output is [B, H/2, W/2] -- each of the four pixels is summed in split order,
+// biased and activated exactly like the unpooled form, then the maximum is taken
+HP3D_KERNEL(256)
+void conv_splitk_reduce_pool_kernel(const float* partial, int ksplit, int B, int H, int W, int Cout, const float* bias, int act,
+                                    float* out, int out_cs, int cout_store) {
+    const int Hp = H / 2, Wp = W / 2;
+    const long npix = (long)B * H * W, total = (long)B * Hp * Wp * cout_store;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % cout_store);
+        long r = i / cout_store;
+        const int ox = (int)(r % Wp); r /= Wp;
+        const int oy = (int)(r % Hp);
+        const int b = (int)(r / Hp);
+        float m = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long pix = ((long)b * H + 2 * oy + (q >> 1)) * W + 2 * ox + (q & 1);
+            float v = 0.f;
+            for (int z = 0; z < ksplit; ++z) v += partial[((size_t)z * npix + pix) * Cout + co];
+            v += bias[co];
+            if (act) v = leaky(v);
+            m = q == 0 ? v : fmaxf(m, v);
+        }
+        out[(((long)b * Hp + oy) * Wp + ox) * out_cs + co] = m;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // 2x2/2 VALID max-pool (utils/general.py:61-65), standalone (the pipeline uses the fused epilogue)
 HP3D_KERNEL(256)
@@ -655,6 +683,11 @@ void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int 
                                float* out, int out_cs, int cout_store, hipStream_t s) {
     HP3D_LAUNCH(conv_splitk_reduce_kernel, dim3(grid_for(npix * cout_store)), dim3(256), 0, s, partial, ksplit, npix,
                 Cout, bias, act, out, out_cs, cout_store);
+}
+void conv_splitk_reduce_pool_launch(const float* partial, int ksplit, int B, int H, int W, int Cout, const float* bias, int act,
+                                    float* out, int out_cs, int cout_store, hipStream_t s) {
+    HP3D_LAUNCH(conv_splitk_reduce_pool_kernel, dim3(grid_for((long)B * (H / 2) * (W / 2) * cout_store)), dim3(256), 0, s, partial, ksplit,
+                B, H, W, Cout, bias, act, out, out_cs, cout_store);
 }
 void maxpool2_launch(const float* x, int B, int H, int W, int C, int in_cs, float* out, hipStream_t s) {
     HP3D_LAUNCH(maxpool2_kernel, dim3(grid_for((long)B * (H / 2) * (W / 2) * C)), dim3(256), 0, s, x, B, H, W, C,

@@ -142,6 +142,9 @@ int conv_mfma_plan(int k, int stride, int Ho, int Wo, int Cin, int Cout, int poo
 // out[pix][co] = act(bias[co] + sum_z partial[z][pix][co]) for co < cout_store
 void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
                                float* out, int out_cs, int cout_store, hipStream_t s);
+// the same + the layer's 2x2 / 2 max-pool: partial = [ksplit][B,H,W][Cout], out = [B,H/2,W/2,out_cs]
+void conv_splitk_reduce_pool_launch(const float* partial, int ksplit, int B, int H, int W, int Cout, const float* bias, int act,
+                                    float* out, int out_cs, int cout_store, hipStream_t s);
 int conv_mfma_launch(const ConvParams& p, int k, int stride, int pool, const ConvPlan& plan, hipStream_t s);
 const char* conv_mfma_variant_name(int k, int stride, int pool, const ConvPlan& plan);
 

@@ -221,7 +221,7 @@ def test_winograd_kernel_on_interpreter(emu_engine, case):
     try:
         emu_engine.set_option('wino_splitk', '0')
         y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
-        emu_engine.set_option('wino_splitk', '1')       # small shapes under-fill the chip: channel steps split (not with a pool)
+        emu_engine.set_option('wino_splitk', '1')       # small shapes under-fill the chip: channel steps split; a pooled layer pools in the reduce
         ys = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
     finally:
         emu_engine.set_option('conv_impl', 'mfma')

@@ -334,6 +334,10 @@ void seg_softmax_kernel(const float* large, int B, int H, int W, unsigned char* 
 // O_0 = {seed};  O_{j+1} = det AND dilate21x21(O_j), j < max(H,W)//10 passes, bit-packed in LDS;
 // stops early at a fix-point (exactly equivalent: the iteration is deterministic).
 // Row r of the bitmap is WW = ceil(W/32) words; pixel x is bit x%32 of word x/32.
+#ifndef HP3D_MG_ABL
+#define HP3D_MG_ABL 0           // timing ablations of mask_grow (wrong results)
+#endif
+constexpr int MG_R = 12;          // rows per thread in the vertical pass of mask_grow
 HP3D_KERNEL(1024)
 void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, int H, int W, int empty_fltmax,
                       float* mask_out, float* center, float* crop_size, float* scale, int* seed_out) {
@@ -374,15 +378,18 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
     if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_cmin = 0x7fffffff; s_cmax = -1; }
     __syncthreads();
 
-    const int num_passes = max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
+    const int num_passes = (HP3D_MG_ABL & 1) ? 0 : max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
     for (int pass = 0; pass < num_passes; ++pass) {
         if (tid == 0) s_changed = 0;
         // horizontal dilation, radius 10
         for (int w = tid; w < NWORD; w += nthr) {
+            if (HP3D_MG_ABL & 2) { tmp[w] = obj[w]; continue; }
             const int wx = w % WW;
-            const unsigned long long lo = wx > 0 ? obj[w - 1] : 0u;
-            const unsigned long long mid = obj[w];
-            const unsigned long long hi = wx + 1 < WW ? obj[w + 1] : 0u;
+            // neighbours read unconditionally (clamped index) and masked afterwards: three independent LDS reads in flight
+            const unsigned lo_r = obj[w > 0 ? w - 1 : 0], mid_r = obj[w], hi_r = obj[w + 1 < NWORD ? w + 1 : w];
+            const unsigned long long lo = wx > 0 ? lo_r : 0u;
+            const unsigned long long mid = mid_r;
+            const unsigned long long hi = wx + 1 < WW ? hi_r : 0u;
             unsigned long long win = (mid << 16) | (lo >> 16) | (hi << 48);
             win = win | (win << 1) | (win >> 1);     // radius 1
             win = win | (win << 2) | (win >> 2);     // radius 3
@@ -391,23 +398,54 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
             tmp[w] = (unsigned)(win >> 16);
         }
         __syncthreads();
-        // vertical dilation, radius 10, AND det
+        // vertical dilation, radius 10, AND det.  A thread owns MG_R consecutive rows of one word column: it reads the
+        // MG_R + 20 rows it needs once and forms the 21-row ORs by doubling (2, 4, 8, 16 rows, then 16 + 4 + 1), ~10 ORs and
+        // 2.7 LDS reads per output instead of 21 + 21
         int changed = 0;
-        for (int w = tid; w < NWORD; w += nthr) {
-            const int y = w / WW;
-            const int ya = max(y - 10, 0), yb = min(y + 10, H - 1);
-            unsigned acc = 0;
-            for (int yy = ya; yy <= yb; ++yy) acc |= tmp[w + (yy - y) * WW];
-            acc &= detb[w];
-            if (acc != obj[w]) changed = 1;
-            // obj is only read through tmp in this phase -> safe to update in place
-            obj[w] = acc;
+        const int nseg = (H + MG_R - 1) / MG_R;
+        for (int u = tid; u < ((HP3D_MG_ABL & 4) ? 0 : nseg * WW); u += nthr) {
+            const int seg = u / WW, wx = u - seg * WW;
+            const int y0 = seg * MG_R;
+            unsigned v[MG_R + 20];
+            // all MG_R + 20 reads are issued unconditionally (rows outside the image read the unit's own first word and are
+            // masked to zero afterwards): no branches, no serialised waits
+            const int base = (y0 - 10) * WW + wx;
+#pragma unroll
+            for (int i = 0; i < MG_R + 20; ++i) {
+                const bool ok = (unsigned)(y0 - 10 + i) < (unsigned)H;
+                const unsigned r = tmp[ok ? base + i * WW : wx];
+                v[i] = ok ? r : 0u;
+            }
+            unsigned a2[MG_R + 17], a4[MG_R + 5];
+            {
+                unsigned a1[MG_R + 19];
+#pragma unroll
+                for (int i = 0; i < MG_R + 19; ++i) a1[i] = v[i] | v[i + 1];
+#pragma unroll
+                for (int i = 0; i < MG_R + 17; ++i) a2[i] = a1[i] | a1[i + 2];
+                unsigned a3[MG_R + 13];
+#pragma unroll
+                for (int i = 0; i < MG_R + 13; ++i) a3[i] = a2[i] | a2[i + 4];
+#pragma unroll
+                for (int i = 0; i < MG_R + 5; ++i) a4[i] = a3[i] | a3[i + 8];
+            }
+#pragma unroll
+            for (int j = 0; j < MG_R; ++j) {
+                const int y = y0 + j;
+                if (y < H) {
+                    const int w = y * WW + wx;
+                    const unsigned acc = (a4[j] | a2[j + 16] | v[j + 20]) & detb[w];     // rows y-10 .. y+10
+                    if (acc != obj[w]) changed = 1;
+                    // obj is only read through tmp in this phase -> safe to update in place
+                    obj[w] = acc;
+                }
+            }
         }
         if (changed) s_changed = 1;
         __syncthreads();
         const int any = s_changed;
         __syncthreads();
-        if (!any) break;
+        if (!any && !(HP3D_MG_ABL & 8)) break;
     }
 
     // bounding box (calc_center_bb): "x" = row index, "y" = column index

@@ -229,10 +229,12 @@ def main():
     eng.set_profiling(0)
 
     if rank == 0:
-        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 / 7x7 layers), conv_mfma (direct implicit GEMM), glue
+        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 / 7x7 layers), conv_mfma (direct implicit GEMM), conv_h16 (the
+        # half-precision 3x3 trunk kernel incl. its pooled and fused-first-block forms), conv_first (conv1_1), glue
         fam = {}
         for name, kern, ms, fl, by in rows:
-            k = 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else kern
+            k = ('conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
+                 'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
             # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
             # nine 3x3 blocks 9*16 per 4*49
             exe = (144.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k == 'conv_wino' else 1.0
@@ -262,6 +264,9 @@ def main():
                     "share_of_gpu_time": round(ms / total_ms, 4)}
         dom = max(fam, key=lambda k: fam[k][0])
         roof = roof_of(dom)
+        if dom == 'conv_h16':
+            roof["note"] = ("half-precision 3x3 trunk kernel (all instantiations: 1 / 2 / 4 cout blocks per wave, pooled, fused conv1_1 + conv1_2); "
+                            "direct form, so executed = algorithmic; the fused launches count conv1_1's FLOPs too")
         if dom == 'conv_wino':
             roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
                             "blocks: 144/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
@@ -270,7 +275,8 @@ def main():
         roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str, a.dtype)
         roof["timing"] = "HIP events on the engine stream around each launch, separate pass of %d steps (%.3f ms/step profiled)" % (
             a.steps, dt_prof / a.steps * 1e3)
-        others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0]) if k != dom and k.startswith('conv')]
+        others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0])
+                  if k != dom and k in ('conv_wino', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')]
         if a.layers:
             agg = {}
             for name, kern, ms_, fl_, by_ in rows:

@@ -79,6 +79,22 @@ def main():
         for k, (n, ms) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
             if ms / tot > 0.002:
                 lines.append('| %s | %d | %.2f | %.1f | %.1f |' % (k, n, ms, ms / n * 1e3, 100 * ms / tot))
+    # HBM traffic per conv_h16 launch at the config-5 per-GPU shape (FETCH_SIZE under-reports wide reads by 2x on gfx950; KiB units)
+    import json
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from summarize_prof import pmc_sum, _tree_id
+    fe = pmc_sum(os.path.join(src, 'c5_FETCH_SIZE', 'hp3d_counter_collection.csv'), 'FETCH_SIZE').get('conv_h16')
+    wr = pmc_sum(os.path.join(src, 'c5_WRITE_SIZE', 'hp3d_counter_collection.csv'), 'WRITE_SIZE').get('conv_h16')
+    if fe and wr and fe[1] and wr[1]:
+        rdb, wtb = 2.0 * fe[0] * 1024 / fe[1], wr[0] * 1024 / wr[1]
+        lines += ['', 'HBM traffic per conv_h16 launch at the config-5 per-GPU shape (B=128, 480x640; separate --pmc FETCH_SIZE / WRITE_SIZE passes, '
+                  'FETCH_SIZE x 2): %.1f MB read + %.1f MB write = %.1f MB (bench.py quotes it as roofline.traffic for that workload).' % (rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6)]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        json.dump({"kernel": "conv_h16", "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
+                   "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, scripts/gpu_pmc_h16.sh",
+                   "stamp": "profile tag %s, summarised %s, tree %s" % (tag, __import__('datetime').date.today().isoformat(), _tree_id()),
+                   "workload": "ColorHandPose3DNetwork.inference, 480x640x3 f32 in HBM, 128 images/GPU/step", "dtype": "f16"},
+                  open(os.path.join(root, 'profiles', 'conv_h16_traffic.json'), 'w'), indent=1)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', tag + '_h16_counters.md')
     open(out, 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))

@@ -489,6 +489,45 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
         gpu_engine.finalize_weights(0)
 
 
+def test_f16_config_c5_shape_properties(gpu_engine, synth_weights):
+    """Config 5's per-GPU input size (480 x 640, half-precision trunks) through size-independent properties, since the oracle
+    needs minutes per image there: the default path (conv_h16 + fused first block) is deterministic, its fused first block is
+    bit-identical to the two-launch form, it agrees with the general half-precision kernel to accumulation order on the
+    HandSegNet logits, and the whole pipeline returns finite keypoints with the same crop decisions on both kernels."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net16 = ColorHandPose3DNetwork(engine=gpu_engine)
+    net16.init_from_dict(synth_weights, dtype='f16')
+    try:
+        B = 8
+        img = synth.make_batch(1000, B, 480, 640)
+        hs = synth.hand_sides(B)
+        n0 = gpu_engine.counter('conv_h16_launches')
+        _, small = gpu_engine.handsegnet(img, want_small=True)
+        assert gpu_engine.counter('conv_h16_launches') - n0 >= 12          # the trunk really ran on conv_h16 (fused block = 1 launch)
+        _, small2 = gpu_engine.handsegnet(img, want_small=True)
+        assert np.array_equal(small, small2)
+        gpu_engine.set_option('f16_fuse12', '0')
+        _, small_unfused = gpu_engine.handsegnet(img, want_small=True)
+        gpu_engine.set_option('f16_fuse12', '1')
+        assert np.array_equal(small, small_unfused)
+        o_h16 = gpu_engine.infer_full(img, hs)
+        gpu_engine.set_option('f16_impl', 'mfma')
+        _, small_mfma = gpu_engine.handsegnet(img, want_small=True)
+        o_mfma = gpu_engine.infer_full(img, hs)
+        gpu_engine.set_option('f16_impl', 'h16')
+        assert np.abs(small - small_mfma).max() < 1e-3
+        assert np.isfinite(o_h16['coord3d']).all() and np.isfinite(o_mfma['coord3d']).all()
+        same = [i for i in range(B) if np.array_equal(o_h16['center'][i], o_mfma['center'][i]) and np.array_equal(o_h16['scale'][i], o_mfma['scale'][i])]
+        assert len(same) >= B // 2                 # random-weight logits sit near the threshold: a flipped edge pixel moves the crop
+        for i in same:
+            assert np.abs(o_h16['coord3d'][i] - o_mfma['coord3d'][i]).max() < 5e-3
+    finally:
+        gpu_engine.set_option('f16_fuse12', '1')
+        gpu_engine.set_option('f16_impl', 'h16')
+        gpu_engine.load_weight_dict(synth_weights)
+        gpu_engine.finalize_weights(0)
+
+
 def test_f16_trunks_config_c5(gpu_engine, synth_weights):
     """BASELINE config 5 precision: half-precision HandSegNet / PoseNet2D trunks (v_mfma_f32_32x32x16_f16, f32
     accumulate), float32 heads / mask stage / lifting.  Checked against the oracle with the same rounding points

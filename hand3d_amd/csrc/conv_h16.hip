@@ -3,18 +3,26 @@
 //
 // Same call sites as conv_mfma.hip's F16 instantiations (NetworkOps.conv_relu + max_pool, utils/general.py:36-65; trunk layer
 // lists nets/ColorHandPose3DNetwork.py:144-157,183-199) and the same arithmetic (v_mfma_f32_32x32x16_f16 on the same packed
-// weights, same row -> pixel map), but built for the half-precision matrix pipe, which consumes operands 16x faster per FLOP
-// than the f32 one.  What the ablations of the general kernel showed (profiles/r02_tuning_notes.md): at 16 MFMAs x 32 cycles
-// per K step its weight LDS-DMA pieces, fragment reads and per-step barrier cost more than the MFMAs.  Hence, like conv_wino:
-//   * ONE wave per SIMD (`__launch_bounds__(256, 1)`), 4 x NT register tiles per wave: 128 pixels x (32 NT) couts, up to 256
-//     accumulators; workgroup = 2 x 2 waves = 16 x 16 output pixels x (64 NT) couts;
+// weights), but built for the half-precision matrix pipe, which consumes operands 16x faster per FLOP than the f32 one.
+// What the ablations of the general kernel showed (profiles/r02_tuning_notes.md): at 16 MFMAs x 32 cycles per K step its weight
+// LDS-DMA pieces, fragment reads and per-step barrier cost more than the MFMAs.  Hence:
+//   * 4 x NT register tiles per wave: 128 pixels x (32 NT) couts; workgroup = 2 x 2 waves = 16 x 16 output pixels x (64 NT)
+//     couts; NT = 4 (Cout % 256 == 0 and Cin >= 512) fills all 256 AGPRs: ONE wave per SIMD, one workgroup per CU;
 //   * weights go global -> VGPR straight in MFMA fragment order (the f16 blob's 1-KB pieces), ring of RING K-steps,
 //     scalar offset per (tap, K-step): no LDS, no DMA issue slots, no barrier for B;
-//   * the 18 x 18 x 64-half input patch (with halo) is DOUBLE buffered in LDS: the next chunk's pieces are in flight during
-//     the current chunk and are committed to the other buffer near its end -- ONE barrier per 64-channel chunk (576 MFMAs per
-//     wave) instead of one per 16;
-//   * the nine taps x four K-steps of a chunk are one straight-line block: every LDS fragment address is base + immediate;
-//   * persistent grid over (image, tile, cout block) items.
+//   * the 18 x 18 x 64-half input patch (with halo) sits in LDS; the nine taps x four K-steps of a chunk are one straight-line
+//     block (every fragment address is base + immediate, fragments prefetched one step ahead): ONE barrier per 64-channel
+//     chunk (576 MFMAs per wave at NT = 4) instead of one per 16; the lane -> patch-pixel map makes every ds_read_b128
+//     conflict-free for the hardware's real 16-lane groups;
+//   * NT = 4: the patch is DOUBLE buffered (the next chunk streams in under the current one in three register groups);
+//     NT <= 2: single buffer and two (NT = 1: three) workgroups per CU -- with 1-4 chunks per item a lone workgroup's load and
+//     store phases are serial latency chains that only another workgroup's MFMAs can cover;
+//   * MFMA issued as D[cout][pixel] (weights = A operand): a lane holds four consecutive couts of a pixel, the epilogue rounds
+//     to half, transposes through per-wave LDS slabs and stores 16 bytes per lane with a pixel's couts contiguous (the pooled
+//     form takes the max of the four pixels' half vectors on the way);
+//   * persistent grid over (image, tile, cout block) items; edges and ragged tiles are out-of-range buffer offsets.
+// Measured (profiles/r02_h16_counters.md): 0.43-0.49 of the 2.5 PF dense peak per instantiation at the config-5 shape; the
+// matrix pipe is busy 0.65-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
 #include "hp3d_common.h"
 #include <algorithm>
 #ifndef HP3D_H16_NT

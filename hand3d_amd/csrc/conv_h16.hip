@@ -25,19 +25,6 @@
 // matrix pipe is busy 0.65-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
 #include "hp3d_common.h"
 #include <algorithm>
-#ifndef HP3D_H16_NT
-#define HP3D_H16_NT 0           // bit 0: patch loads non-temporal, bit 1: output stores non-temporal
-#endif
-#if HP3D_H16_NT & 1
-#define H16_LOAD_IN HP3D_BUFFER_LOAD16_NT
-#else
-#define H16_LOAD_IN HP3D_BUFFER_LOAD16
-#endif
-#if HP3D_H16_NT & 2
-#define H16_STORE_OUT HP3D_BUFFER_STORE16_NT
-#else
-#define H16_STORE_OUT HP3D_BUFFER_STORE16
-#endif
 #ifndef HP3D_H16_ABL
 #define HP3D_H16_ABL 0          // timing ablations (scripts/build_variant.sh); any non-zero value computes wrong results
 #endif
@@ -173,7 +160,7 @@ void conv_h16_kernel(const ConvParams p) {
         auto patch_fetch = [&](int chunk, int g) {
 #pragma unroll
             for (int j = 0; j < HPGS; ++j)
-                if (g * HPGS + j < HPVEC) preg[j] = H16_LOAD_IN(irsrc, poff[g * HPGS + j], chunk * 128);
+                if (g * HPGS + j < HPVEC) preg[j] = HP3D_BUFFER_LOAD16(irsrc, poff[g * HPGS + j], chunk * 128);
         };
         auto patch_commit = [&](int buf, int g) {
 #pragma unroll
@@ -211,7 +198,7 @@ void conv_h16_kernel(const ConvParams p) {
         auto load_chunk = [&](int chunk) {
             f32x4 first[HPVEC];
 #pragma unroll
-            for (int v = 0; v < HPVEC; ++v) first[v] = H16_LOAD_IN(irsrc, poff[v], chunk * 128);
+            for (int v = 0; v < HPVEC; ++v) first[v] = HP3D_BUFFER_LOAD16(irsrc, poff[v], chunk * 128);
 #pragma unroll
             for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, chunk * 4 + (s & 3));
 #pragma unroll
@@ -390,7 +377,7 @@ void conv_h16_kernel(const ConvParams p) {
                     }
                     const int yp = yb >> 1, xp = (ox0 >> 1) + pp;
                     const int off = (cok && pp < 8 && yp < Hs && xp < Ws) ? (yp * Ws + xp) * px_b + cbyte : OOR;
-                    H16_STORE_OUT(orsrc, __builtin_bit_cast(f32x4, m), off, 0);
+                    HP3D_BUFFER_STORE16(orsrc, __builtin_bit_cast(f32x4, m), off, 0);
                 }
             } else {
                 constexpr int PPR = 64 / G;                                  // pixels per round: 4 / 8 / 16
@@ -400,7 +387,7 @@ void conv_h16_kernel(const ConvParams p) {
                     const f32x4 v = *(const f32x4*)(sl + sp * SPITCH + g * 16);
                     const int y = yb + ((r * PPR) >> 4), x = ox0 + sp0 + ((r * PPR) & 15);
                     const int off = (cok && y < Hs && x < Ws) ? (y * Ws + x) * px_b + cbyte : OOR;
-                    H16_STORE_OUT(orsrc, v, off, 0);
+                    HP3D_BUFFER_STORE16(orsrc, v, off, 0);
                 }
             }
         }

@@ -69,12 +69,6 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
-// the same with the non-temporal hint (streamed once: activations passing through, so that they do not displace the
-// weights every workgroup of the XCD re-reads from its L2)
-#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) \
-    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 2))
-#define HP3D_BUFFER_STORE16_NT(rsrc, val4, voff, soff) \
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, (val4)), (rsrc), (voff), (soff), 2)
 // 4 B per lane from (rsrc base + per-lane voff + scalar soff); out-of-range offsets read 0
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 0))
@@ -94,8 +88,6 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
-#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) HP3D_BUFFER_LOAD16(rsrc, voff, soff)
-#define HP3D_BUFFER_STORE16_NT(rsrc, val4, voff, soff) HP3D_BUFFER_STORE16(rsrc, val4, voff, soff)
 #define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) ((void)(rsrc), (void)(half_val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
 #endif

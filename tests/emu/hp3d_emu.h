@@ -87,8 +87,6 @@ static inline void hp3d_emu_buffer_store16(hp3d_rsrc_t r, f32x4 v, unsigned voff
     if (voff < r.bytes && voff + soff + 16u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 16);
 }
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) hp3d_emu_buffer_store16((rsrc), (val4), (unsigned)(voff), (unsigned)(soff))
-#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) HP3D_BUFFER_LOAD16(rsrc, voff, soff)
-#define HP3D_BUFFER_STORE16_NT(rsrc, val4, voff, soff) HP3D_BUFFER_STORE16(rsrc, val4, voff, soff)
 #define HP3D_GLDS16(gptr, lds_wave_base, lane) memcpy((float*)(lds_wave_base) + (lane) * 4, (gptr), 16)
 extern float* hp3d_emu_smem;
 #define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem

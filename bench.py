@@ -8,6 +8,7 @@ the only collectives are the one-off RCCL weight broadcast (untimed setup) and t
 [B,21,3] keypoints (timed).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 20 --warmup 5          (self-launch: spawns the 8 ranks itself, see self_launch())
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -65,43 +66,70 @@ def _cpu_model():
     return 'unknown'
 
 
-def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s):
-    """rank 0, N = 1 only: the oracle (CPU restatement of the reference; SURVEY.md 8d recipe: NumPy glue + torch-CPU /
-    oneDNN convolutions on all cores) over the FIRST images of the very batch the GPU just processed -- one pass gives the
-    reported CPU baseline (bounded sample) and the parity of the GPU outputs against it (mean EPE, EvalUtil semantics)."""
+def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s, alg_flop_per_image):
+    """rank 0, N = 1 only, two things on the very batch the GPU just processed:
+    * `cpu_baseline` (kind "port"): the path as a BATCHED torch-CPU / oneDNN program (oracle/torch_port.py: the whole batch
+      through every layer in one call, NCHW tensors kept in torch across layers, vectorised glue) -- SURVEY.md 8d's "CPU path
+      timed beside it".  One untimed pass (oneDNN primitive creation), then whole-batch passes for about half the budget;
+    * `epe_vs_oracle`: the strict oracle (oracle/nets.py: NumPy glue, one image per call) over the first images for the other
+      half -- mean EPE (EvalUtil semantics) and worst heat-map / 3-D keypoint deviation of the GPU outputs."""
     import torch                                   # the baseline itself is torch-CPU; nothing else in this file uses it
     from oracle import general as OG
     from oracle import nets as onets
     from oracle import tf_ops as OT
+    from oracle import torch_port as TP
     # thread count: SURVEY.md 8d says "all cores"; on many-core hosts (and in containers whose CPU quota is below nproc)
-    # that over-subscribes oneDNN badly, so a mid-size layer (conv3_2-like, 80x80, 256 -> 256) picks the best of a few counts
-    OT.CONV_BACKEND = 'torch'
+    # that over-subscribes oneDNN badly, so a mid-size layer (conv3_2-like, 80x80, 256 -> 256, 8 images) picks the best of a few
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    xs = np.random.default_rng(0).standard_normal((1, 80, 80, 256)).astype(np.float32)
-    ws = weights['HandSegNet/conv3_2/weights']
+    port = TP.TorchPort(weights)
+    xs = torch.from_numpy(np.random.default_rng(0).standard_normal((8, 256, 80, 80)).astype(np.float32))
+    probe_flop = 2.0 * 9 * 256 * 256 * 6400 * 8
     best = (1e30, 1)
-    for nt in sorted({ncpu, max(ncpu // 2, 1), 64, 32, 16, 8}):
-        if nt > ncpu:
-            continue
-        torch.set_num_threads(nt)
-        OT.conv2d_same(xs, ws)
-        t0 = time.time()
-        OT.conv2d_same(xs, ws)
-        OT.conv2d_same(xs, ws)
-        best = min(best, ((time.time() - t0) / 2, nt))
+    with torch.no_grad():
+        for nt in sorted({ncpu, max(ncpu // 2, 1), 128, 64, 32, 16, 8}):
+            if nt > ncpu:
+                continue
+            torch.set_num_threads(nt)
+            port.conv(xs, 'HandSegNet/conv3_2')
+            t0 = time.time()
+            port.conv(xs, 'HandSegNet/conv3_2')
+            port.conv(xs, 'HandSegNet/conv3_2')
+            best = min(best, ((time.time() - t0) / 2, nt))
     torch.set_num_threads(best[1])
+    probe_gflops = probe_flop / best[0] / 1e9
+    run = (lambda: port.inference(imgs, hs)) if workload == 'full' else (lambda: port.pose2d(imgs))
+    t0 = time.time()
+    run()                                          # untimed: oneDNN creates its primitives per shape on the first call
+    t_first = time.time() - t0
+    passes, t_used = 0, 0.0
+    while passes == 0 or t_used + t_used / passes <= budget_s / 2:
+        t0 = time.time()
+        run()
+        t_used += time.time() - t0
+        passes += 1
+    n_img = imgs.shape[0]
+    rate = passes * n_img / t_used
+    cores = torch.get_num_threads()
+    cpu = {"value": round(rate, 3), "unit": "images/s", "cores": cores, "kind": "port",
+           "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
+           "achieved_gflops": round(rate * alg_flop_per_image / 1e9, 1), "conv_probe_gflops": round(probe_gflops, 1),
+           "sample": "%d pass(es) over the same %d-image batch (%.1f s; first, untimed pass %.1f s) through the batched torch-CPU / "
+                     "oneDNN float32 port of the path (oracle/torch_port.py), torch.set_num_threads(%d) = the fastest of a few "
+                     "counts on a conv3_2-sized layer (%.0f GFLOP/s there) -- a CPU restatement baseline, not TensorFlow 1.3"
+                     % (passes, n_img, t_used, t_first, cores, probe_gflops)}
+    # ---- parity of the GPU outputs against the strict oracle (per image)
+    OT.CONV_BACKEND = 'torch'
     util = OG.EvalUtil()
     worst_kp3d = worst_map = 0.0
-    n, t_used = 0, 0.0
+    n, t_par = 0, 0.0
     try:
-        OT.conv2d_same(imgs[:1, :32, :32], weights['HandSegNet/conv1_1/weights'])                # thread-pool / oneDNN warm-up
-        while n < imgs.shape[0] and (n == 0 or t_used + t_used / n <= budget_s):
+        while n < imgs.shape[0] and (n == 0 or t_par + t_par / n <= budget_s / 2):
             t0 = time.time()
             if workload == 'full':
                 o = onets.inference(weights, imgs[n:n + 1], hs[n:n + 1], True)
             else:
                 o = onets.posenet2d(weights, imgs[n:n + 1])
-            t_used += time.time() - t0
+            t_par += time.time() - t0
             if workload == 'full':
                 util.feed(o[5][0], np.ones(21), gpu_out['coord3d'][n])
                 worst_kp3d = max(worst_kp3d, float(np.abs(o[5][0] - gpu_out['coord3d'][n]).max()))
@@ -111,12 +139,6 @@ def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s):
             n += 1
     finally:
         OT.CONV_BACKEND = 'numpy'
-    cores = torch.get_num_threads()
-    cpu = {"value": round(n / t_used, 4), "unit": "images/s", "cores": cores, "kind": "port",
-           "cpu_model": _cpu_model(), "host_cores": os.cpu_count(),
-           "sample": "%d image(s) of the same batch through the oracle (NumPy glue + torch-CPU/oneDNN float32 convolutions, "
-                     "torch.set_num_threads(%d) = the fastest of a few counts on a conv3_2-sized layer: %.0f GFLOP/s), %.1f s -- "
-                     "a CPU restatement baseline, not TensorFlow 1.3" % (n, cores, 2 * 9 * 256 * 256 * 6400 / best[0] / 1e9, t_used)}
     par = {"images": n, "max_abs_err_heatmap32": worst_map, "tolerance_heatmap": 1e-3}
     if workload == 'full':
         par.update({"mean_epe": float(util.get_measures(0.0, 0.05, 20)[0]), "max_abs_err_kp3d": worst_kp3d,
@@ -143,8 +165,75 @@ def traffic_record(dom, workload_str, dtype):
         return None, None
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (N > 1) with no launcher in the environment: start the N ranks ourselves -- one process per
+    GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / MASTER_PORT=<free port> exactly as torch.distributed.run
+    would export them, plus a per-run random HP3D_RDZV_SECRET for the TCP rendezvous -- forward rank 0's JSON line and
+    return the worst exit code.  (The reference has no counterpart: one tf.Session, run.py:50.)"""
+    import secrets
+    import socket
+    import subprocess
+    sk = socket.socket()
+    sk.bind(('127.0.0.1', 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    entry = os.environ.get('HP3D_BENCH_ENTRY', os.path.abspath(__file__))     # tests substitute a stand-in engine
+    base = dict(os.environ, WORLD_SIZE=str(a.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                HP3D_RDZV_SECRET=secrets.token_hex(16), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    procs = []
+    for r in range(a.gpus):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        # rank 0's stdout carries the ONE JSON line; whatever another rank prints goes to stderr
+        procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b''
+    rcs = [None] * a.gpus
+    first_fail = None
+    try:
+        while any(rc is None for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None and p.poll() is not None:
+                    rcs[r] = p.returncode
+                    if p.returncode != 0 and first_fail is None:
+                        first_fail = time.time()
+                        sys.stderr.write('bench.py: rank %d exited with code %d\n' % (r, p.returncode))
+            if rcs[0] is None:
+                try:                                    # drain rank 0's pipe while waiting (one JSON line: small)
+                    o, _ = procs[0].communicate(timeout=0.2)
+                    out0 += o or b''
+                except subprocess.TimeoutExpired:
+                    pass
+            else:
+                time.sleep(0.2)
+            # a rank that died leaves the others waiting at the rendezvous / in a collective: give them 20 s, then stop them
+            if first_fail is not None and time.time() - first_fail > 20.0:
+                for r, p in enumerate(procs):
+                    if rcs[r] is None:
+                        p.kill()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if procs[0].stdout is not None:
+        try:
+            out0 += procs[0].stdout.read() or b''
+        except (OSError, ValueError):
+            pass
+    sys.stdout.write(out0.decode(errors='replace'))
+    sys.stdout.flush()
+    bad = [rc for rc in rcs if rc]
+    return 0 if not bad else max(abs(rc) for rc in bad)
+
+
 def main():
     a = parse()
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    if a.gpus > 1 and not launched:
+        sys.exit(self_launch(a))
+    if launched and int(os.environ.get('WORLD_SIZE', '1')) != a.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report a line whose '
+                         'n_gpus would not be what was asked for\n' % (a.gpus, os.environ.get('WORLD_SIZE', '1')))
+        sys.exit(2)
     # keep stdout for the ONE JSON line: route everything else (RCCL's version banner, library chatter)
     # written to fd 1 during the run to stderr
     sys.stdout.flush()
@@ -153,7 +242,6 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
     from hand3d_amd import Engine, synth, arch
@@ -180,6 +268,10 @@ def main():
         sp.use_tcp_only()
         eng.load_weight_dict(synth.make_weights())
         eng.finalize_weights(a.dtype)
+    # what RCCL itself says the communicator spans (ncclCommCount through hp3d_get_counter): 0 = no communicator
+    rccl_ranks = eng.counter('comm_ranks') if comm_mode == 'rccl' else 0
+    if comm_mode == 'rccl' and rccl_ranks != world:
+        raise RuntimeError('RCCL communicator spans %d ranks, the launcher started %d' % (rccl_ranks, world))
     if a.graph:
         eng.set_option('graph', '1')
     for kv in a.option:
@@ -322,7 +414,9 @@ def main():
                 gpu_out['sm32'] = eng.to_host(d_kpmap, (nchk, 256, 256, 21))[:, ::8, ::8]
             else:
                 gpu_out['sm32'] = eng.to_host(d_sm[2], (B, 32, 32, 21))
-            cpu, parity = oracle_leg(weights, img_np[:32], hs_np[:32], gpu_out, a.workload, a.cpu_seconds)
+            fl_ = arch.pipeline_flops(H, W)
+            cpu, parity = oracle_leg(weights, img_np[:32], hs_np[:32], gpu_out, a.workload, a.cpu_seconds,
+                                     fl_['total'] if a.workload == 'full' else fl_['posenet'])
         n_img = B * world * a.steps
         fl_img = arch.pipeline_flops(H, W)
         res = {
@@ -335,7 +429,7 @@ def main():
                        "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                        "parallelism": "batch-shard x%d, one process per GPU, no data-path collective; weights by hp3d_bcast_weights "
                                       "and a per-step keypoint all-gather (RCCL through the C ABI, TCP rendezvous; no torch)" % world,
-                       "comm": comm_mode, "hipgraph": bool(a.graph), "options": a.option,
+                       "comm": comm_mode, "rccl_ranks": rccl_ranks, "hipgraph": bool(a.graph), "options": a.option,
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
             "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu, "epe_vs_oracle": parity,
             "host_path": host_path,

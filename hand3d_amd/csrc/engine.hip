@@ -1078,6 +1078,8 @@ static std::string graph_key(const char* what, std::initializer_list<long> dims,
     return k;
 }
 
+static long long comm_ranks(hp3d_ctx* ctx);     // ranks of the live RCCL communicator (ncclCommCount), 0 = none
+
 extern "C" {
 
 int hp3d_abi_version(void) { return 1; }
@@ -1843,6 +1845,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);
 }
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {
@@ -1875,6 +1878,7 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;       // optional: the communicator's own idea of its size
 };
 Rccl* rccl(hp3d_ctx* ctx) {
     static Rccl R;
@@ -1891,6 +1895,7 @@ Rccl* rccl(hp3d_ctx* ctx) {
     R.AllGather = (decltype(R.AllGather))dlsym(h, "ncclAllGather");
     R.CommDestroy = (decltype(R.CommDestroy))dlsym(h, "ncclCommDestroy");
     R.GetErrorString = (decltype(R.GetErrorString))dlsym(h, "ncclGetErrorString");
+    R.CommCount = (decltype(R.CommCount))dlsym(h, "ncclCommCount");
     if (!R.GetUniqueId || !R.CommInitRank || !R.Broadcast || !R.AllGather || !R.CommDestroy || !R.GetErrorString) {
         set_error(ctx, "librccl lacks an expected symbol");
         return nullptr;
@@ -2036,3 +2041,16 @@ uint32_t hp3d_crc32c(const void* data, size_t n) {
 }
 
 }  // extern "C"
+
+static long long comm_ranks(hp3d_ctx* ctx) {
+#ifndef HP3D_EMU
+    if (!ctx || !ctx->comm) return 0;
+    Rccl* R = rccl(ctx);
+    int n = 0;
+    if (R && R->CommCount && R->CommCount((ncclComm_t)ctx->comm, &n) == ncclSuccess) return n;
+    return ctx->comm_size;
+#else
+    (void)ctx;
+    return 0;
+#endif
+}

@@ -13,8 +13,9 @@ also carries the host-side scalars of the benchmark protocol (barrier, max of th
 The torch.distributed helpers at the bottom (`broadcast_blob`, `gather_keypoints`) remain for callers that already
 live inside a torch process group (and for the gloo CPU test); nothing in the product path imports torch.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
@@ -34,18 +35,114 @@ def shard_sizes(n_items, world):
 
 
 # ------------------------------------------------------------------------------------------- TCP rendezvous
-_MAGIC = b'HP3DRDZV1'
+_MAGIC = b'HP3DRDZV2'
+_MAX_MSG = 1 << 28            # 256 MB: far above anything the protocol carries (ids, scalars, keypoint arrays)
+
+
+# Wire format of the payloads: a small tagged encoding of exactly the value kinds the protocol carries (None, bool, int,
+# float, str, bytes, ndarray, list / tuple, dict with str keys).  Nothing a peer sends is ever executed or un-pickled.
+def _enc(obj, out):
+    if obj is None:
+        out.append(b'N')
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b'T' if obj else b'F')
+    elif isinstance(obj, (int, np.integer)):
+        out.append(b'I' + struct.pack('<q', int(obj)))
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b'D' + struct.pack('<d', float(obj)))
+    elif isinstance(obj, str):
+        b = obj.encode('utf-8')
+        out.append(b'S' + struct.pack('<Q', len(b)) + b)
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        b = bytes(obj)
+        out.append(b'B' + struct.pack('<Q', len(b)) + b)
+    elif isinstance(obj, np.ndarray):
+        if obj.dtype.hasobject:
+            raise TypeError("rendezvous: object arrays cannot be sent")
+        ds = obj.dtype.str.encode('ascii')
+        raw = np.ascontiguousarray(obj).tobytes()
+        out.append(b'A' + struct.pack('<BB', len(ds), obj.ndim) + ds + struct.pack('<%dq' % obj.ndim, *obj.shape) +
+                   struct.pack('<Q', len(raw)) + raw)
+    elif isinstance(obj, (list, tuple)):
+        out.append(b'L' + struct.pack('<Q', len(obj)))
+        for x in obj:
+            _enc(x, out)
+    elif isinstance(obj, dict):
+        out.append(b'M' + struct.pack('<Q', len(obj)))
+        for k, v in obj.items():
+            if not isinstance(k, str):
+                raise TypeError("rendezvous: dict keys must be str")
+            _enc(k, out)
+            _enc(v, out)
+    else:
+        raise TypeError("rendezvous: cannot send %r" % type(obj))
+
+
+def _dec(buf, pos):
+    tag = buf[pos:pos + 1]
+    pos += 1
+    if tag == b'N':
+        return None, pos
+    if tag in (b'T', b'F'):
+        return tag == b'T', pos
+    if tag == b'I':
+        return struct.unpack_from('<q', buf, pos)[0], pos + 8
+    if tag == b'D':
+        return struct.unpack_from('<d', buf, pos)[0], pos + 8
+    if tag in (b'S', b'B'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos:
+            raise ValueError("rendezvous: truncated message")
+        raw = bytes(buf[pos:pos + n])
+        return (raw.decode('utf-8') if tag == b'S' else raw), pos + n
+    if tag == b'A':
+        ld, nd = struct.unpack_from('<BB', buf, pos)
+        pos += 2
+        dt = np.dtype(bytes(buf[pos:pos + ld]).decode('ascii'))
+        pos += ld
+        if dt.hasobject:
+            raise ValueError("rendezvous: object arrays are refused")
+        shape = struct.unpack_from('<%dq' % nd, buf, pos)
+        pos += 8 * nd
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos or any(d < 0 for d in shape) or n != int(np.prod(shape, dtype=np.int64)) * dt.itemsize:
+            raise ValueError("rendezvous: bad array header")
+        return np.frombuffer(buf, dtype=dt, count=n // dt.itemsize, offset=pos).reshape(shape).copy(), pos + n
+    if tag in (b'L', b'M'):
+        (n,) = struct.unpack_from('<Q', buf, pos)
+        pos += 8
+        if n > len(buf) - pos:              # every element takes at least one byte
+            raise ValueError("rendezvous: truncated message")
+        if tag == b'L':
+            out = []
+            for _ in range(n):
+                x, pos = _dec(buf, pos)
+                out.append(x)
+            return out, pos
+        d = {}
+        for _ in range(n):
+            k, pos = _dec(buf, pos)
+            v, pos = _dec(buf, pos)
+            if not isinstance(k, str):
+                raise ValueError("rendezvous: bad dict key")
+            d[k] = v
+        return d, pos
+    raise ValueError("rendezvous: unknown tag %r" % tag)
 
 
 def _send_msg(sock, obj):
-    data = pickle.dumps(obj, protocol=4)
+    parts = []
+    _enc(obj, parts)
+    data = b''.join(parts)
     sock.sendall(struct.pack('<Q', len(data)) + data)
 
 
 def _recv_exact(sock, n):
     buf = bytearray()
     while len(buf) < n:
-        chunk = sock.recv(n - len(buf))
+        chunk = sock.recv(min(n - len(buf), 1 << 20))
         if not chunk:
             raise ConnectionError("rendezvous peer closed the connection")
         buf += chunk
@@ -54,7 +151,13 @@ def _recv_exact(sock, n):
 
 def _recv_msg(sock):
     (n,) = struct.unpack('<Q', _recv_exact(sock, 8))
-    return pickle.loads(_recv_exact(sock, n))
+    if n > _MAX_MSG:
+        raise ValueError("rendezvous: message of %d bytes refused" % n)
+    buf = _recv_exact(sock, n)
+    obj, pos = _dec(buf, 0)
+    if pos != n:
+        raise ValueError("rendezvous: trailing bytes in message")
+    return obj
 
 
 def rendezvous_ports(master_port):
@@ -64,20 +167,44 @@ def rendezvous_ports(master_port):
     return [1024 + (base - 1024 + 977 + 131 * k) % (65536 - 1024) for k in range(8)]
 
 
-class Rendezvous(object):
-    """Star over TCP with rank 0 as the hub: allgather / broadcast / barrier of small Python objects.  World size 1
-    needs no socket.  Single node, trusted peers (the launcher's processes): pickle is used for the payload."""
+def _is_loopback(addr):
+    return addr in ('localhost', '::1') or addr.startswith('127.')
 
-    def __init__(self, rank, world, addr='127.0.0.1', port=29500, timeout=300.0, token=None):
+
+def _mac(secret, *parts):
+    return hmac.new(secret, b'|'.join(parts), hashlib.sha256).digest()
+
+
+class Rendezvous(object):
+    """Star over TCP with rank 0 as the hub: allgather / broadcast / barrier of small values (None, numbers, str, bytes,
+    ndarrays, lists, str-keyed dicts -- a fixed tagged encoding, nothing is un-pickled).  World size 1 needs no socket.
+
+    Joining is a fixed-size challenge-response, checked BEFORE any payload is parsed: the hub sends a 16-byte nonce, the
+    spoke answers magic + rank + HMAC-SHA256(secret, nonce | rank | world), the hub proves itself with
+    HMAC(secret, nonce | "hub").  `secret` comes from the launcher (env HP3D_RDZV_SECRET: bench.py's self-launch draws a
+    random one per run); without it the key is only the public "port:world" string, which keeps strangers' stray
+    connections and foreign listeners apart but authenticates nobody -- so the hub then insists on a loopback address
+    unless HP3D_RDZV_ALLOW_REMOTE=1."""
+
+    def __init__(self, rank, world, addr='127.0.0.1', port=29500, timeout=300.0, token=None, secret=None):
         self.rank, self.world = int(rank), int(world)
         self.peers = {}          # hub: rank -> socket
         self.sock = None         # spoke: socket to the hub
         self.token = (token if token is not None else '%s:%d' % (port, self.world))
         if self.world == 1:
             return
+        if secret is None:
+            secret = os.environ.get('HP3D_RDZV_SECRET')
+        has_secret = bool(secret)
+        key = (secret if has_secret else self.token)
+        key = key if isinstance(key, bytes) else str(key).encode('utf-8')
+        wtag = str(self.world).encode('ascii')
         ports = rendezvous_ports(port)
         deadline = time.time() + timeout
         if self.rank == 0:
+            if not has_secret and not _is_loopback(addr) and os.environ.get('HP3D_RDZV_ALLOW_REMOTE') != '1':
+                raise RuntimeError("rendezvous: refusing to listen on %s without HP3D_RDZV_SECRET (set it on every rank, or "
+                                   "HP3D_RDZV_ALLOW_REMOTE=1 on a trusted network)" % addr)
             srv = None
             for p in ports:
                 try:
@@ -101,18 +228,24 @@ class Rendezvous(object):
                     continue
                 try:
                     c.settimeout(10.0)
-                    hello = _recv_exact(c, len(_MAGIC))
-                    msg = _recv_msg(c) if hello == _MAGIC else None
-                    if not msg or msg.get('token') != self.token or not (0 < msg.get('rank', 0) < self.world) \
-                            or msg['rank'] in self.peers:
+                    nonce = os.urandom(16)
+                    c.sendall(_MAGIC + nonce)
+                    hello = _recv_exact(c, len(_MAGIC) + 4 + 32)          # fixed size; nothing is parsed before the MAC holds
+                    (prank,) = struct.unpack('<I', hello[len(_MAGIC):len(_MAGIC) + 4])
+                    ok = hello[:len(_MAGIC)] == _MAGIC and 0 < prank < self.world and prank not in self.peers and \
+                        hmac.compare_digest(hello[len(_MAGIC) + 4:], _mac(key, nonce, str(prank).encode('ascii'), wtag))
+                    if not ok:
                         c.close()
                         continue
-                    c.sendall(_MAGIC)
+                    c.sendall(_mac(key, nonce, b'hub'))
                     c.settimeout(timeout)
                     c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    self.peers[msg['rank']] = c
-                except (OSError, ConnectionError, pickle.UnpicklingError, EOFError):
-                    c.close()
+                    self.peers[prank] = c
+                except Exception:                # a stranger, a scanner, a half-open connection: drop it, keep listening
+                    try:
+                        c.close()
+                    except Exception:
+                        pass
             srv.close()
         else:
             k = 0
@@ -121,19 +254,24 @@ class Rendezvous(object):
                     raise TimeoutError("rendezvous: rank %d could not reach rank 0 on %s ports %s" % (self.rank, addr, ports))
                 p = ports[k % len(ports)]
                 k += 1
+                s = None
                 try:
                     s = socket.create_connection((addr, p), timeout=2.0)
                     s.settimeout(10.0)
-                    s.sendall(_MAGIC)
-                    _send_msg(s, {'token': self.token, 'rank': self.rank})
-                    if _recv_exact(s, len(_MAGIC)) != _MAGIC:
+                    first = _recv_exact(s, len(_MAGIC) + 16)
+                    if first[:len(_MAGIC)] != _MAGIC:
                         raise ConnectionError("not a rendezvous hub")
+                    nonce = first[len(_MAGIC):]
+                    s.sendall(_MAGIC + struct.pack('<I', self.rank) + _mac(key, nonce, str(self.rank).encode('ascii'), wtag))
+                    if not hmac.compare_digest(_recv_exact(s, 32), _mac(key, nonce, b'hub')):
+                        raise ConnectionError("the listener does not hold the rendezvous secret")
                     s.settimeout(timeout)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                     self.sock = s
                 except (OSError, ConnectionError):
                     try:
-                        s.close()
+                        if s is not None:
+                            s.close()
                     except Exception:
                         pass
                     if k % len(ports) == 0:

@@ -215,7 +215,8 @@ int hp3d_prof_get(hp3d_ctx* ctx, int i, char* name, int name_cap, char* kernel, 
 int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
 /* Executor counters: "graph_captures" / "graph_replays" = hipGraphs instantiated / launched since hp3d_create (option
  * "graph" = "1"; a replay happens only with per-launch profiling off); "conv_h16_launches" = half-precision trunk
- * layers that ran on conv_h16.hip (option "f16_impl").                                                            */
+ * layers that ran on conv_h16.hip (option "f16_impl"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
+ * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);
 
 /* ---- multi-GPU: one process and one context per GPU, RCCL over xGMI ---------

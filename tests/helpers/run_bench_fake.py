@@ -32,6 +32,8 @@ class FakeEngine(object):
     log = []
 
     def __init__(self, device=0, path=None):
+        if os.environ.get('HP3D_FAKE_DIE_RANK') == os.environ.get('RANK', '-'):
+            raise RuntimeError('no HIP device visible (fake): rank %s dies before the rendezvous' % os.environ.get('RANK'))
         self.device, self.h, self.lib = device, 1, None
         self.rank = self.world = None
         self.prof = 0
@@ -100,9 +102,10 @@ class FakeEngine(object):
         return np.zeros(world * count, np.float32)
 
     def counter(self, name):
-        return 0
+        return (self.world or 0) if name == 'comm_ranks' else 0
 
 
+os.environ['HP3D_BENCH_ENTRY'] = os.path.abspath(__file__)      # bench.py's self-launch starts THIS script per rank
 hand3d_amd.Engine = FakeEngine
 _lib.Engine = FakeEngine
 sys.argv = ['bench.py'] + sys.argv[1:]

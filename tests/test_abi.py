@@ -63,3 +63,78 @@ def test_product_never_imports_oracle_or_frameworks():
     code = "import sys; sys.path.insert(0, %r); import hand3d_amd, hand3d_amd.nets, hand3d_amd.utils.general; " \
            "assert 'oracle' not in sys.modules and 'torch' not in sys.modules and 'tensorflow' not in sys.modules" % ROOT
     subprocess.check_call([sys.executable, '-c', code])
+
+
+def _kernel_disassembly(tmp_path):
+    """{kernel symbol: [instruction lines]} of the gfx950 code object inside libhp3d.so."""
+    import glob
+    import shutil
+    from hand3d_amd import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    lib = str(tmp_path / 'libhp3d.so')          # --offloading extracts the device bundles next to its input
+    shutil.copy(_lib.DEFAULT_LIB, lib)
+    subprocess.run([objdump, '--offloading', lib], capture_output=True, text=True, cwd=str(tmp_path))
+    cos = [f for f in glob.glob(str(tmp_path / '*')) if 'gfx950' in os.path.basename(f) and f != lib]
+    assert cos, "no gfx950 code object extracted from libhp3d.so"
+    kernels = {}
+    for co in cos:
+        out = subprocess.run([objdump, '-d', '--no-show-raw-insn', co], capture_output=True, text=True).stdout
+        cur = None
+        for line in out.splitlines():
+            m = re.match(r'^[0-9a-f]+ <(.+)>:$', line.strip())
+            if m:
+                cur = kernels.setdefault(m.group(1), [])
+            elif cur is not None and line.strip() and not line.startswith('Disassembly'):
+                cur.append(line.strip())
+    return kernels
+
+
+def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_path):
+    """The miscompile of round 2 (profiles/r02_tuning_notes.md, "conv_wino"): when hipcc cannot prove a buffer load's scalar offset
+    wave-uniform it wraps the load in a waterfall loop (v_readfirstlane ... s_and_saveexec ... s_cbranch_execnz), and one such build
+    returned WRONG 7x7 results on the GPU while the CPU interpreter of the same source was right.  So the shipped code object is
+    disassembled: in every conv_wino / conv_h16 kernel (a) no s_cbranch_execnz sits within a few instructions of a buffer load
+    (no waterfall loop), and (b) no scratch access lies inside the MFMA phase of a step / chunk loop (a spilled accumulator or
+    address there drains the weight ring and has produced the slow builds recorded in the tuning notes)."""
+    kernels = _kernel_disassembly(tmp_path)
+    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino_kernel|conv_h16_kernel', k)}
+    assert len(hot) >= 8, sorted(kernels)[:20]
+    for name, ins in hot.items():
+        ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]
+        n_mfma = sum(o.startswith('v_mfma') for o in ops)
+        assert n_mfma > 0, name
+        for i, o in enumerate(ops):
+            if o == 's_cbranch_execnz':
+                near = ops[max(0, i - 12):i + 1]
+                assert not any(x.startswith(('buffer_load', 'buffer_store', 'global_load')) for x in near), \
+                    "%s: waterfall loop around a memory instruction (s_cbranch_execnz at instruction %d)" % (name, i)
+        # loops = backward branches; the innermost loop that issues MFMAs (the step / chunk loop) must not touch scratch
+        # (the persistent per-item loop around them may: per-item addresses are allowed to live in scratch)
+        addr = {}
+        for i, l in enumerate(ins):
+            m = re.search(r'//\s*([0-9A-Fa-f]+):', l)
+            if m:
+                addr[int(m.group(1), 16)] = i
+        first = min(addr) if addr else 0
+        loops = []
+        for i, l in enumerate(ins):
+            if not ops[i].startswith(('s_cbranch', 's_branch')):
+                continue
+            m = re.search(r'<[^>]*\+0x([0-9a-fA-F]+)>', l)     # objdump prints the target as <symbol+0xoff>
+            if not m:
+                continue
+            tgt = addr.get(first + int(m.group(1), 16))
+            if tgt is not None and tgt < i and any(o.startswith('v_mfma') for o in ops[tgt:i + 1]):
+                loops.append((tgt, i))
+        assert loops, "%s: no loop around its MFMAs found (disassembly format changed?)" % name
+        # the tightest loop around MFMAs = the step loop (conv_wino) / chunk loop (conv_h16); the first step of an item is peeled
+        # off in front of it and the persistent item loop lies around both
+        for t, i in [min(loops, key=lambda ti: ti[1] - ti[0])]:
+            # the MFMA phase of the loop body = first .. last MFMA (the 16 planes of a Winograd step, the 36 tap-steps of a
+            # half-precision chunk).  Outside it the present kernels do keep a few per-item / per-block addresses in scratch
+            # (conv_h16's single-buffer forms reload patch addresses in their load phase, the 7x7 Winograd form re-bases its
+            # window offsets at a block switch) -- known and measured, see profiles/r02_tuning_notes.md.
+            mf = [k for k in range(t, i + 1) if ops[k].startswith('v_mfma')]
+            lo, hi = mf[0], mf[-1]
+            bad = [ins[k] for k in range(lo, hi + 1) if ops[k].startswith('scratch_')]
+            assert not bad, "%s: scratch traffic inside an MFMA loop: %s" % (name, bad[:4])

@@ -78,3 +78,39 @@ def test_bench_protocol_single_process_plain():
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec['n_gpus'] == 1 and rec['host_path'] is not None
     assert 'comm_init' not in out.stderr            # no launcher -> no communicator
+
+
+def test_bench_self_launch_spawns_the_ranks():
+    """`python bench.py --gpus 3 ...` with NO launcher in the environment (the shape of the driver's N = 1 command): bench.py starts
+    the three ranks itself, rank 0's JSON line comes out of the parent, and it says 3 GPUs and a 3-rank communicator."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HP3D_RDZV_SECRET', 'HP3D_BENCH_ENTRY')}
+    out = subprocess.run([sys.executable, HELPER, '--gpus', '3', '--steps', '3', '--warmup', '1', '--batch', '2', '--height', '16',
+                          '--width', '16'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 3 and rec['config']['global_batch'] == 6 and rec['config']['comm'] == 'rccl'
+    assert rec['config']['rccl_ranks'] == 3 and rec['value'] > 0
+    logs = [l for l in out.stderr.splitlines() if l.startswith('FAKELOG rank')]
+    assert sorted(l.split(':')[0] for l in logs) == ['FAKELOG rank 0', 'FAKELOG rank 1', 'FAKELOG rank 2'], out.stderr[-2000:]
+    for l in logs:
+        assert 'comm_init' in l and 'bcast' in l
+
+
+def test_bench_self_launch_propagates_a_failing_rank():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HP3D_RDZV_SECRET', 'HP3D_BENCH_ENTRY')}
+    env['HP3D_FAKE_DIE_RANK'] = '1'
+    out = subprocess.run([sys.executable, HELPER, '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
+                          '--width', '16'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert out.stdout.strip() == '', "no JSON line when a rank failed"
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    out = subprocess.run([sys.executable, HELPER, '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
+                          '--width', '16'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 2 and 'WORLD_SIZE' in out.stderr and out.stdout.strip() == ''

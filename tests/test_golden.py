@@ -132,3 +132,31 @@ def test_kernels_on_interpreter_match_reference_code_fixtures(emu_engine, synth_
     mean, median, auc, pck, thr = u.get_measures(0.0, 30.0, 20)
     assert np.isclose(mean, e['mean'], rtol=1e-13) and np.isclose(median, e['median'], rtol=1e-13)
     assert np.isclose(auc, e['auc'], rtol=1e-13) and np.allclose(pck, e['pck'], rtol=1e-13) and np.array_equal(thr, e['thresholds'])
+
+
+def test_c5_fixture_is_the_oracle_at_config5_size_and_precision(synth_weights):
+    """tests/golden/c5_f16_480x640.npz (scripts/make_c5_fixture.py) re-derived for its second image: 480x640, trunks rounding to
+    half where the engine stores halves (oracle/nets.py f16=True), float64 accumulation -- the fixture the GPU test of BASELINE
+    config 5 reads is exactly what the oracle computes (~20 s)."""
+    g = np.load(os.path.join(GOLD, 'c5_f16_480x640.npz'))
+    i = 1
+    img = synth.make_batch(int(g['seed0']) + i, 1, 480, 640)
+    hs = synth.hand_sides(2)[i:i + 1]
+    small, large = N.handsegnet(synth_weights, img, acc=np.float64, f16=True)
+    assert np.array_equal(small, g['seg_small'][i:i + 1])
+    fg, det = G.fg_and_detmap(large[-1])
+    assert np.array_equal(np.packbits(det.reshape(1, -1).astype(np.uint8), axis=1)[0], g['det'][i])
+    margin = np.abs(large[-1][..., 1] - large[-1][..., 0])
+    assert np.array_equal(np.minimum(np.floor(margin * 1e4), 255).astype(np.uint8)[0], g['margin_q'][i])
+    mask = G.single_obj_scoremap(large[-1], early_exit=True)
+    assert np.array_equal(np.packbits(mask.reshape(1, -1).astype(np.uint8), axis=1)[0], g['mask'][i])
+    cen, _, best = G.calc_center_bb(mask)
+    sc = G.scale_from_crop_size(best, 256)
+    assert np.array_equal(cen, g['center'][i:i + 1]) and np.array_equal(sc, g['scale_crop'][i:i + 1])
+    sms = N.posenet2d(synth_weights, G.crop_image_from_xy(img, cen, 256, scale=sc), acc=np.float64, f16=True)
+    for k in range(3):
+        assert np.array_equal(sms[k], g['sm32'][k][i:i + 1])
+    coord3d, _, _ = N.pose3d(synth_weights, sms[-1], hs, acc=np.float64)
+    assert np.array_equal(coord3d, g['coord3d'][i:i + 1])
+    # the half-precision configuration stays inside its own bar against the float32 path on these frames
+    assert np.abs(g['sm32'][2] - g['sm32_f32']).max() < 5e-3 and np.abs(g['coord3d'] - g['coord3d_f32']).max() < 5e-3

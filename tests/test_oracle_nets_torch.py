@@ -155,3 +155,31 @@ def test_lifting_composition(weights):
     assert np.abs(can.numpy() - rcan).max() < 1e-5
     assert np.abs(R.numpy() - rR).max() < 1e-5
     assert np.abs(coord.numpy() - rel).max() < 1e-5
+
+
+def test_batched_cpu_port_equals_the_oracle():
+    """oracle/torch_port.py -- the batched torch-CPU program bench.py times as `cpu_baseline` -- against the strict oracle on two
+    config-1 images: same mask decisions (centre, scale), heat-maps / 3-D keypoints inside the path's tolerances, the same
+    arg-max keypoints; plus the engineered mask cases (two blobs 10 / 11 pixels apart, empty, full, border) through its
+    vectorised growth."""
+    from oracle import general as G
+    from oracle import torch_port as TP
+    w = synth.make_weights()
+    img = synth.make_batch(0, 2, 240, 320)
+    hs = synth.hand_sides(2)
+    o = TP.TorchPort(w).inference(img, hs)
+    r = N.inference(w, img, hs, True)
+    assert np.array_equal(o['center'], r[3]) and np.abs(o['scale_crop'] - r[2]).max() < 1e-6
+    assert np.abs(o['hand_scoremap'] - r[0]).max() < 1e-4 and np.abs(o['image_crop'] - r[1]).max() < 1e-4
+    assert np.abs(o['keypoints_scoremap'].permute(0, 2, 3, 1).numpy() - r[4]).max() < 1e-3
+    assert np.abs(o['keypoint_coord3d'] - r[5]).max() < 1e-4
+    for i in range(2):
+        assert np.array_equal(o['kp_crop'][i], G.detect_keypoints(r[4][i]).astype(np.int64))
+    port = TP.TorchPort(w)
+    for case in synth.MASK_CASES:
+        sm = synth.blob_scoremap(case)
+        m, c, s = port.mask_center_scale(torch.from_numpy(sm).permute(0, 3, 1, 2))
+        ref = G.single_obj_scoremap(sm)
+        rc, _, rs = G.calc_center_bb(ref)
+        assert np.array_equal(m.numpy()[0], ref[0, :, :, 0] > 0.5), case
+        assert np.array_equal(c.numpy(), rc) and np.abs(s.numpy() - G.scale_from_crop_size(rs, 256)[:, 0]).max() < 1e-6, case

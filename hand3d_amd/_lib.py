@@ -7,6 +7,7 @@ an interpreter of the same kernel sources; see tests/emu/hp3d_emu.h).
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 
@@ -130,6 +131,8 @@ class DevBuf(object):
 
     def __init__(self, engine, ptr, nbytes):
         self.engine, self.ptr, self.nbytes = engine, ptr, nbytes
+        if engine is not None and hasattr(engine, '_devbufs'):
+            engine._devbufs.add(self)         # Engine.close() releases whatever is still alive (ptr becomes 0)
 
     def __int__(self):
         return self.ptr
@@ -164,9 +167,15 @@ class Engine(object):
         self.h = h
         self.device = device
         self._pinned = []
+        self._devbufs = weakref.WeakSet()
 
     def close(self):
+        """Destroys the context.  Device buffers handed out by dev_alloc / to_device that are still alive are freed here
+        (their `ptr` becomes 0), and so are the page-locked buffers behind pinned_empty(): arrays returned by pinned_empty()
+        must not be touched after close() -- hp3d_host_free waits for pending uploads first."""
         if getattr(self, 'h', None):
+            for b in list(getattr(self, '_devbufs', [])):
+                b.free()
             for p in getattr(self, '_pinned', []):
                 self.lib.hp3d_host_free(self.h, C.c_void_p(p))
             self._pinned = []
@@ -491,7 +500,8 @@ class Engine(object):
         return out
 
     def pinned_empty(self, shape, dtype=np.float32):
-        """NumPy array over page-locked host memory (for hp3d_upload_async); keep the returned array alive."""
+        """NumPy array over page-locked host memory (for hp3d_upload_async).  The memory belongs to the engine: it is released
+        by close() (after pending uploads have finished), so the array must not be used past that point."""
         n = int(np.prod(shape)) * np.dtype(dtype).itemsize
         p = C.c_void_p()
         self._chk(self.lib.hp3d_host_alloc(self.h, n, C.byref(p)))

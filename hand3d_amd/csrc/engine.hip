@@ -944,6 +944,17 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
     HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(k->stream, ctx->ev_fork, 0));
     auto off = [&](float* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
+    // Whatever happens below, the parent's stream must not run ahead of (and hp3d_sync / hp3d_dev_free / hp3d_destroy must
+    // cover) what was already enqueued on the child's stream: the join is recorded and waited for on EVERY exit path.
+    struct Join {
+        hp3d_ctx *p, *k;
+        ~Join() {
+            if (hipEventRecord(p->ev_join, k->stream) == hipSuccess) (void)hipStreamWaitEvent(p->stream, p->ev_join, 0);
+            else (void)hipStreamSynchronize(k->stream);
+        }
+    } join{ctx, k};
+    // (host buffers: the child's pageable device->host copies block the host, so the two halves overlap on the `_dev`
+    //  entry points only -- the ones bench.py and dist.py use)
     int rc = infer_full_chunked1(k, b1, H, W, image ? image + (size_t)b0 * H * W * 3 : nullptr, hand_side + (size_t)b0 * 2,
                                  off(hand_scoremap, (size_t)H * W * 2), off(image_crop, 256 * 256 * 3), off(scale_crop, 1),
                                  off(center, 2), off(kp_scoremap, 256 * 256 * 21), off(coord3d, 63), off(hand_mask, (size_t)H * W),
@@ -952,11 +963,13 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
     if (rc != 0) { set_error(ctx, k->err.c_str()); }
     const int rc0 = rc != 0 ? rc : infer_full_chunked1(ctx, b0, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center,
                                                        kp_scoremap, coord3d, hand_mask, dev, image_u8, Hin, Win, kp_crop, kp_image, true);
-    // ... and the parent's stream continues only after the child's half is done
-    HIPCHK(ctx, hipEventRecord(ctx->ev_join, k->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-    if (!dev) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return rc0;
+    if (rc0 != 0) return rc0;
+    // ... and the parent's stream continues only after the child's half is done (host buffers: wait for both here)
+    if (!dev) {
+        HIPCHK(ctx, hipStreamSynchronize(k->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return 0;
 #else
     return HP3D_ERR_UNSUPPORTED;
 #endif
@@ -1112,6 +1125,9 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     if (!ctx) return HP3D_ERR_ARG;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+#ifndef HP3D_EMU
+    if (ctx->copy_stream) hipStreamSynchronize(ctx->copy_stream);
+#endif
     if (ctx->kid) { hp3d_destroy(ctx->kid); ctx->kid = nullptr; }
 #ifndef HP3D_EMU
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
@@ -1175,6 +1191,8 @@ int hp3d_dev_free(hp3d_ctx* ctx, void* p) {
     if (!p) return 0;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));    // a pending hp3d_upload_async may target it
+    if (ctx->kid) HIPCHK(ctx, hipStreamSynchronize(ctx->kid->stream));
     HIPCHK(ctx, hipFree(p));
     return 0;
 }
@@ -1189,7 +1207,11 @@ int hp3d_host_alloc(hp3d_ctx* ctx, size_t bytes, void** out) {
 }
 int hp3d_host_free(hp3d_ctx* ctx, void* p) {
     if (!ctx) return HP3D_ERR_ARG;
-    if (p) HIPCHK(ctx, hipHostFree(p));
+    if (!p) return 0;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->copy_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));    // an upload may still be reading the buffer
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipHostFree(p));
     return 0;
 }
 int hp3d_upload_async(hp3d_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
@@ -1503,6 +1525,7 @@ int hp3d_infer_2d_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, flo
     const int mb = mb0 <= 0 ? B : std::min(mb0, B);
     CHK(ensure_arena(ctx, mb, H, W));
     const int saved_prof = ctx->profiling;
+    struct ProfRestore { hp3d_ctx* c; int v; ~ProfRestore() { c->profiling = v; } } prof_restore{ctx, saved_prof};   // every exit path
     if (ctx->profiling != 2) prof_reset(ctx);   // mode 2 accumulates across calls
     for (int b0 = 0; b0 < B; b0 += mb) {
         const int nb = std::min(mb, B - b0);
@@ -1521,7 +1544,6 @@ int hp3d_infer_2d_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, flo
         if (scale_crop) CHK(copy_out(ctx, scale_crop + b0, ctx->d_scale, (size_t)nb, false));
         if (center) CHK(copy_out(ctx, center + (size_t)b0 * 2, ctx->d_center, (size_t)nb * 2, false));
     }
-    ctx->profiling = saved_prof;
     return finish_op(ctx);
 }
 int hp3d_infer_2d(hp3d_ctx* ctx, int B, int H, int W, const float* image, float* keypoints_scoremap,

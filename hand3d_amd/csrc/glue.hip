@@ -626,8 +626,12 @@ void bone_rel_inv_kernel(const float* rel, int B, float* xyz) {
 }
 
 // detect_keypoints (utils/general.py:331-344): first arg-max per channel; one workgroup per (b,c)
+// order-preserving key of a float for np.argmax's ordering: -0.0 and +0.0 are equal (the first one wins), and a NaN beats
+// everything (np.argmax returns the first NaN)
 __device__ __forceinline__ unsigned ord_f32(float f) {
-    const unsigned u = __float_as_uint(f);
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;       // NaN, either sign
+    if ((u & 0x7FFFFFFFu) == 0u) u = 0u;                           // -0.0 -> +0.0
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 HP3D_KERNEL(256)

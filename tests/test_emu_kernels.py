@@ -293,3 +293,28 @@ def test_device_detect_keypoints_equals_reference_on_upsampled_map(emu_engine):
     sm = rng.standard_normal((1, 30, 40, 5)).astype(np.float32)
     up = T.resize_bilinear_legacy(sm, 100, 90)
     assert np.array_equal(emu_engine.detect_keypoints(sm, (100, 90))[0], PG.detect_keypoints(up[0]))
+
+
+def test_argmax_ordering_of_signed_zeros_and_nans_is_numpys(emu_engine):
+    """np.argmax treats -0.0 and +0.0 as equal (the first one wins) and returns the first NaN; the device keys do too
+    (the raw bit pattern ordered -0.0 below +0.0 and a sign-bit NaN lowest)."""
+    from hand3d_amd.utils import general as PG
+    x = np.full((1, 8, 8, 4), -1.0, np.float32)
+    x[0, :, :, 0] = 0.0
+    x[0, 2, 3, 0] = -0.0          # an all-zero map with mixed signs: index 0 wins
+    x[0, 0, 0, 1] = -0.0
+    x[0, 5, 5, 1] = 0.0           # -0.0 at (0,0) comes first and is not smaller
+    x[0, 3, 1, 2] = 7.0
+    x[0, 4, 4, 2] = np.float32(np.nan)                      # a NaN beats the finite maximum
+    x[0, 6, 6, 3] = -np.float32(np.nan)                     # ... with either sign
+    x[0, 1, 1, 3] = np.inf
+    got = emu_engine.argmax2d(x)
+    for c in range(4):
+        v, u = np.unravel_index(np.argmax(x[0, :, :, c]), (8, 8))
+        assert tuple(got[0, c]) == (v, u), c
+    # the same through the fused up-sample + arg-max: zeros of both signs interpolate to zeros of both signs
+    z = np.zeros((1, 4, 4, 2), np.float32)
+    z[0, 1:, :, 0] = -0.0
+    z[0, 2, 2, 1] = -0.0
+    up = T.resize_bilinear_legacy(z, 32, 32)
+    assert np.array_equal(emu_engine.detect_keypoints(z, (32, 32))[0], PG.detect_keypoints(up[0]))

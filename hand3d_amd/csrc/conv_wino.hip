@@ -237,6 +237,7 @@ void conv_wino_kernel(const ConvParams p) {
     split_of(item, kz, cy, tblock);
     int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
     const int sub0 = SPLITK ? HP3D_READFIRSTLANE(s0 / csteps) : 0;
+    int sub_cur = sub0;
     loader_setup(tblock, true, sub0);
     table_write(tblock, 0, kz);
     int wvoff = (cy * (COUTS / 32) + wcout) * 4096 + lane * 16;
@@ -260,6 +261,11 @@ void conv_wino_kernel(const ConvParams p) {
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool lasts = step + 1 == s1;
+            // block (i, j) = (sub_cur / 3, sub_cur % 3) of the 9x9 extension this step's channels belong to
+            const bool za = sub_cur >= 6, zb = sub_cur == 2 || sub_cur == 5 || sub_cur == 8;
+            const int skip_a = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR(za ? 1 : 0) : 0;
+            const int skip_b = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR(zb ? 1 : 0) : 0;
+            const int skip_ab = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR((za || zb) ? 1 : 0) : 0;
             // Loads return in issue order (one vmcnt counter), so the first wait on a weight fragment issued AFTER
             // the window loads also waits for the windows: the ring is topped up to 4 planes (0..3) first, the
             // windows go next, and B(p+4) is issued behind plane p's MFMAs -- the windows (the next step's, or the
@@ -281,15 +287,26 @@ void conv_wino_kernel(const ConvParams p) {
             for (int pl = 0; pl < 16; ++pl) {           // fully unrolled: accumulator and ring indices are static
                 HP3D_SCHED_BARRIER();
                 if (pl < 15) a_fetch((pl & 1) ^ 1, pl + 1);
-                if (FIRST) {
-                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], zero);
-                } else {
-                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], M[pl]);
-                }
+                // 7x7 filters: in the edge blocks of the zero-extended 9x9 filter (i = 2 or j = 2: one filter row / column of
+                // three) the transformed filter G g G^T has a zero row a = 3 / column b = 3, i.e. planes 12..15 / 3, 7, 11, 15
+                // contribute nothing: 121 instead of 144 plane-steps per item.  Their MFMAs are skipped (not on an item's
+                // first step, which also zero-initialises the accumulators).
+                const bool zplane = NSUB == 9 && !FIRST && ((pl >> 2) == 3 || (pl & 3) == 3);
+                if (zplane) {
+                    const int skip = pl == 15 ? skip_ab : (pl >> 2) == 3 ? skip_a : skip_b;
 #pragma unroll
-                for (int gj = 1; gj < 4 * G; ++gj)
-                    M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
+                    for (int g = 0; g < G; ++g) HP3D_MFMA4_UNLESS(M[pl], af[pl & 1][g], bq[pl & 3][g], skip);
+                } else {
+                    if (FIRST) {
+                        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], zero);
+                    } else {
+                        M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][0][0], bq[pl & 3][0][0], M[pl]);
+                    }
+#pragma unroll
+                    for (int gj = 1; gj < 4 * G; ++gj)
+                        M[pl] = HP3D_MFMA_32x32x2(af[pl & 1][gj >> 2][gj & 3], bq[pl & 3][gj >> 2][gj & 3], M[pl]);
+                }
                 if (pl == 0) {               // the window loads are issued between plane 0's MFMAs, not in front of them
                     window_fetch(NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (WCK * 4)) : ncs * (WCK * 4));   // (uniform; hipcc cannot always tell)
                     HP3D_SCHED_GROUP(HP3D_SG_DS_READ, G);
@@ -311,6 +328,7 @@ void conv_wino_kernel(const ConvParams p) {
             __syncthreads();             // V[cur^1] complete, V[cur] free
 #endif
             cur ^= 1;
+            sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };
         step_body(s0, std::true_type{});
         {   // the next item (its tile table is written here, hidden under this item's MFMAs)

@@ -25,6 +25,32 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
 // 16-B fragments (held as f32x4) reinterpreted as 8 halves: lane l carries k = 8*(l>>5) .. 8*(l>>5)+7
 #define HP3D_MFMA_32x32x16_F16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+// four dependent v_mfma_f32_32x32x2_f32 on one accumulator tuple (an accumulate chain), skipped as a whole when the wave-uniform
+// `skip` is non-zero.  The branch lives INSIDE the statement so that the compiler sees one opaque read-modify-write of the
+// accumulator: a source-level `if` around 16 MFMAs makes hipcc merge two versions of a 16-register tuple at the join and it
+// answers with AGPR <-> scratch copies (profiles/r01_tuning_notes.md, "7x7 mode: skip ...").  Operands come from LDS / buffer
+// loads (the compiler's s_waitcnt in front of the statement covers them); the accumulator's previous writer and next reader
+// are MFMAs of the same chain or lie a whole step away.
+#define HP3D_MFMA4_UNLESS(acc, a4, b4, skip)                                                                       \
+    asm volatile("s_cmp_lg_u32 %9, 0\n\t"                                                                          \
+                 "s_cbranch_scc1 .Lhp3d_skip%=\n\t"                                                                \
+                 "v_mfma_f32_32x32x2_f32 %0, %1, %5, %0\n\t"                                                       \
+                 "v_mfma_f32_32x32x2_f32 %0, %2, %6, %0\n\t"                                                       \
+                 "v_mfma_f32_32x32x2_f32 %0, %3, %7, %0\n\t"                                                       \
+                 "v_mfma_f32_32x32x2_f32 %0, %4, %8, %0\n"                                                          \
+                 ".Lhp3d_skip%=:"                                                                                   \
+                 : "+a"(acc)                                                                                        \
+                 : "v"((a4)[0]), "v"((a4)[1]), "v"((a4)[2]), "v"((a4)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]),   \
+                   "v"((b4)[3]), "s"(skip)                                                                           \
+                 : "scc")
+// a wave-uniform int held in an SGPR that the compiler cannot trace back to a VGPR (it does propagate
+// __builtin_amdgcn_readfirstlane's argument into an inline-asm "s" operand and then fails to assemble)
+static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
+    int s;
+    asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(uniform_value));
+    return s;
+}
+#define HP3D_OPAQUE_SGPR(x) hp3d_opaque_sgpr(x)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

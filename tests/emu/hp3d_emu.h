@@ -54,6 +54,7 @@ static inline int hp3d_num_cus() { return 3; }     // small on purpose: persiste
 #define HP3D_SG_DS_READ 0x100
 #define HP3D_SCHED_GROUP(kind, n) ((void)0)
 #define HP3D_READFIRSTLANE(x) (x)
+#define HP3D_OPAQUE_SGPR(x) (x)
 #define HP3D_WAIT_VMCNT0() ((void)0)
 struct hp3d_rsrc_t { const char* base; unsigned bytes; };
 #define HP3D_MAKE_RSRC(ptr, bytes) hp3d_rsrc_t{(const char*)(ptr), (unsigned)(bytes)}
@@ -108,6 +109,12 @@ f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
 #define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))
 f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
 #define HP3D_MFMA_32x32x16_F16(a, b, c) hp3d_emu_mfma_32x32x16_f16((a), (b), (c))
+// skip must be uniform over the wave (every fiber takes the same branch, so the collective MFMA stays collective)
+#define HP3D_MFMA4_UNLESS(acc, a4, b4, skip)                                                        \
+    do {                                                                                           \
+        if (!(skip))                                                                               \
+            for (int _e = 0; _e < 4; ++_e) (acc) = hp3d_emu_mfma_32x32x2((a4)[_e], (b4)[_e], (acc)); \
+    } while (0)
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }
 

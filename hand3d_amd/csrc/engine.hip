@@ -49,6 +49,7 @@ struct ConvL {
     int ek, cin_pad, cout_pad;
     size_t w_off, b_off;   // offsets into the blob (floats)
     size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
+    size_t ww2_off = 0;    // the same filters in conv_wino2.hip's fragment order (two workgroups per CU), 0 = none
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
     size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
     int net;
@@ -83,6 +84,8 @@ struct Tables {
         // Winograd F(2x2,3x3) copy (16 planes; a 7x7 filter as nine 3x3 blocks along the channel axis)
         if (stride == 1 && cout % 64 == 0 && ((k == 3 && l.mode == 0) || (k == 7 && (l.mode == 0 || l.mode == 2)))) {
             l.ww_off = blob_floats;
+            blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
+            l.ww2_off = blob_floats;
             blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
         }
         if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
@@ -252,10 +255,13 @@ struct hp3d_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int use_h16 = 1;           // half-precision 3x3 trunk layers on conv_h16.hip (option "f16_impl" = "h16" | "mfma")
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
+    bool two_streams_live = false;   // set while a whole-path call runs its two halves on two streams (kernel choice: wino2_auto)
+    int use_wino2 = -1;        // conv_wino2.hip (two workgroups per CU): -1 auto (short reductions, under-filled launches), 0 never, 1 wherever eligible (option "wino2")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
     int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12")
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
+    long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
                                // 32 in float32 mode, no split with half-precision trunks -- measured optima)
@@ -437,6 +443,33 @@ void same_pad(int in, int k, int stride, int* out, int* before) {
     *before = total / 2;
 }
 
+// Which Winograd kernel a layer takes when both can run it (option "wino2" = "auto"): a small cost model in units of one CU-time of
+// conv_wino.hip's item-step (32 tiles x 128 couts x 32 channels), fitted to per-layer timings of both kernels at B = 1 ... 32
+// (profiles/r03_tuning_notes.md).  conv_wino.hip walks ceil(items / CUs) rounds of whole items; conv_wino2.hip's items are a quarter
+// of that work each, two run per CU, so its time is the balanced share plus one small item of tail -- it wins where the coarse rounds
+// quantise badly (300 items on 256 CUs) and at small batches, and loses ~7 % on long filled launches (twice the window traffic and
+// input-transform work per MFMA).  `old_nt` / `old_ks`: conv_wino_eligible's answer for the same layer (0: it would not run).
+bool wino2_auto(int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int old_nt, int old_ks, int ks2, bool two_streams) {
+    if ((long)B * Ho * Wo < 512) return false;              // 16 x 16 maps and below: one direct launch beats split + reduce
+    if (!old_nt) return true;
+    const double cus = hp3d_num_cus(), reduce_cost = 0.7, c2 = 1.07;
+    const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+    const int nsub = k == 7 ? 9 : 1;
+    const long items1 = (tiles + old_nt - 1) / old_nt * (cout_pad / (old_nt == 32 ? 128 : 64));
+    const int S1 = nsub * cin_pad / (old_nt == 32 ? 32 : 16);
+    const double w1 = old_nt == 32 ? 1.0 : 0.5;
+    const double t_old = old_ks > 1 ? std::ceil((double)S1 / old_ks) * w1 * std::max(1.0, items1 * old_ks / cus) + reduce_cost
+                                    : std::ceil(items1 / cus) * S1 * w1;
+    const long items2 = (tiles + 31) / 32 * (cout_pad / 64);
+    const int S2 = nsub * cin_pad / 16;
+    const double t_new = ks2 > 1 ? c2 * (std::ceil((double)S2 / ks2) * 0.25 * std::max(1.0, items2 * ks2 / cus)) + reduce_cost
+                                 : c2 * (items2 * S2 * 0.25 / cus + S2 * 0.125);
+    // with a second stream on the GPU the other half's kernels fill conv_wino.hip's tail rounds anyway (measured: B = 16 as 8 + 8
+    // loses 2 % when its filled layers switch): only under-filled launches are candidates then
+    if (two_streams && old_ks <= 1) return false;
+    return t_new < 0.97 * t_old;
+}
+
 // ---- one convolution layer -------------------------------------------------------------------
 // in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
 // f16 = 1 (trunk nets after hp3d_finalize_weights(dtype=1)): `in` / `out` hold halves (except the raw image of
@@ -450,9 +483,45 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
     const double bytes = (f16 ? 2.0 : 4.0) * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
                                 (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
-    int wino_ks = 1;
-    if (ctx->use_wino && !f16 && l.ww_off &&
-        conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino_ks : nullptr)) {
+    int wino_ks = 1, wino2_ks = 1;
+    const int old_nt = (ctx->use_wino && !f16 && l.ww_off) ? conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool,
+                                                                                 ctx->wino_splitk ? &wino_ks : nullptr) : 0;
+    if (ctx->use_wino && ctx->use_wino2 && !f16 && l.ww2_off && !ctx->conv_naive &&
+        conv_wino2_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino2_ks : nullptr) &&
+        (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live))) {
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.ww2_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = wino2_ks; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.nsub = l.k == 7 ? 9 : 1;
+        if (wino2_ks > 1) {
+            const size_t need = (size_t)wino2_ks * B * Ho * Wo * l.cout_pad;
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+            p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
+        }
+        {
+            ProfScope ps(ctx, l.name, l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
+                                      : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3", flops, bytes);
+            if (conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (2 workgroups per CU): launch refused");
+        }
+        ++ctx->conv_wino2_launches;
+        if (wino2_ks > 1) {
+            ProfScope ps(ctx, l.name, pool ? "conv_splitk_reduce_pool" : "conv_splitk_reduce", 0.0, 4.0 * (wino2_ks + 1) * B * Ho * Wo * l.cout_pad);
+            if (pool)
+                conv_splitk_reduce_pool_launch(ctx->col, wino2_ks, B, Ho, Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                               std::min(l.cout_pad, out_cs), ctx->stream);
+            else
+                conv_splitk_reduce_launch(ctx->col, wino2_ks, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                          std::min(l.cout_pad, out_cs), ctx->stream);
+        }
+    } else if (old_nt) {
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + l.ww_off; p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -920,7 +989,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -946,9 +1015,11 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
     auto off = [&](float* p, size_t per) { return p ? p + (size_t)b0 * per : nullptr; };
     // Whatever happens below, the parent's stream must not run ahead of (and hp3d_sync / hp3d_dev_free / hp3d_destroy must
     // cover) what was already enqueued on the child's stream: the join is recorded and waited for on EVERY exit path.
+    ctx->two_streams_live = k->two_streams_live = true;
     struct Join {
         hp3d_ctx *p, *k;
         ~Join() {
+            p->two_streams_live = k->two_streams_live = false;
             if (hipEventRecord(p->ev_join, k->stream) == hipSuccess) (void)hipStreamWaitEvent(p->stream, p->ev_join, 0);
             else (void)hipStreamSynchronize(k->stream);
         }
@@ -1255,6 +1326,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
     if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
@@ -1350,6 +1422,7 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
                 else if (e < 149) cmap[e] = e - 128;
             }
             wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww_off);
+            wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww2_off);
         }
     }
     for (const FcL& l : ctx->T.fc) {
@@ -1669,8 +1742,34 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
-    int op_ks = 1;
-    if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks : nullptr) && Cout % 64 == 0) {
+    int op_ks = 1, op_ks2 = 1;
+    if (ctx->use_wino && ctx->use_wino2 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
+        conv_wino2_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr)) {
+        // option "wino2" = "1": the two-workgroups-per-CU Winograd kernel (conv_wino2.hip)
+        const size_t wn = wino_packed_floats(k, l.cin_pad, l.cout_pad);
+        std::vector<float> pw(wn + l.cout_pad, 0.f);
+        wino2_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
+        for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
+        float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
+        ConvParams p;
+        p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + wn; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = act; p.im2col = 0; p.ksplit = op_ks2; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
+        p.nsub = k == 7 ? 9 : 1;
+        float* d_part = nullptr;
+        if (op_ks2 > 1) {
+            d_part = S.alloc<float>((size_t)op_ks2 * B * Ho * Wo * Cout); NN(ctx, d_part);
+            p.out = d_part;
+        }
+        if (conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (2 workgroups per CU): launch refused");
+        ++ctx->conv_wino2_launches;
+        if (op_ks2 > 1 && pool)
+            conv_splitk_reduce_pool_launch(d_part, op_ks2, B, Ho, Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
+        else if (op_ks2 > 1)
+            conv_splitk_reduce_launch(d_part, op_ks2, (long)B * Ho * Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
+    } else if (ctx->use_wino && !ctx->conv_naive && conv_wino_eligible(ctx->use_wino, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks : nullptr) && Cout % 64 == 0) {
         const size_t wn = wino_packed_floats(k, l.cin_pad, l.cout_pad);
         std::vector<float> pw(wn + l.cout_pad, 0.f);
         wino_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
@@ -1867,6 +1966,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);
 }

@@ -11,6 +11,7 @@
 #include "hp3d_emu.h"
 #else
 #include <hip/hip_runtime.h>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 hp3d_f16;
@@ -22,6 +23,8 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
 #define HP3D_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__)
 #define HP3D_MFMA_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+// v_mfma_f32_16x16x4_f32: A[i][k] in lane i + 16 k, B[k][j] in lane j + 16 k, D reg r of lane l: column l & 15, row 4 (l >> 4) + r
+#define HP3D_MFMA_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 // 16-B fragments (held as f32x4) reinterpreted as 8 halves: lane l carries k = 8*(l>>5) .. 8*(l>>5)+7
 #define HP3D_MFMA_32x32x16_F16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
@@ -43,6 +46,24 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  : "v"((a4)[0]), "v"((a4)[1]), "v"((a4)[2]), "v"((a4)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]),   \
                    "v"((b4)[3]), "s"(skip)                                                                           \
                  : "scc")
+// the same for conv_wino2.hip's plane: eight v_mfma_f32_16x16x4_f32 (two accumulator tuples alternating, four k groups), skipped as
+// a whole when `skip` is non-zero.  Its accumulators live in arch VGPRs (the kernel has no AGPRs), hence "+v".
+#define HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, skip)                                                        \
+    asm volatile("s_cmp_lg_u32 %14, 0\n\t"                                                                         \
+                 "s_cbranch_scc1 .Lhp3d_skip%=\n\t"                                                                \
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %6, %10, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %11, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %8, %12, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %13, %1\n"                                                         \
+                 ".Lhp3d_skip%=:"                                                                                   \
+                 : "+v"(acc0), "+v"(acc1)                                                                           \
+                 : "v"((a0)[0]), "v"((a0)[1]), "v"((a0)[2]), "v"((a0)[3]), "v"((a1)[0]), "v"((a1)[1]), "v"((a1)[2]),   \
+                   "v"((a1)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]), "s"(skip)                     \
+                 : "scc")
 // a wave-uniform int held in an SGPR that the compiler cannot trace back to a VGPR (it does propagate
 // __builtin_amdgcn_readfirstlane's argument into an inline-asm "s" operand and then fails to assemble)
 static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
@@ -51,12 +72,19 @@ static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
     return s;
 }
 #define HP3D_OPAQUE_SGPR(x) hp3d_opaque_sgpr(x)
+// in-launch hand-off between workgroups (cdna_hip_programming.md Guideline 16, R1 in its counter form): the producers store their
+// payload write-through (HP3D_BUFFER_STORE4_SC1) and drain it (vmcnt(0) in every wave, then a barrier), one lane takes a ticket
+// with a relaxed agent-scope atomic; the last arriver acquires at agent scope (one lane, then a barrier) before plain loads.
+// (A release FENCE instead of write-through stores is correct too but writes back the whole L2 of the XCD per workgroup:
+//  measured 140 us per launch with 512 workgroups, profiles/r03_tuning_notes.md.)
+#define HP3D_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#define HP3D_TICKET_AGENT(ptr) __hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define HP3D_STORE_RELAXED_AGENT(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
 // keeps a per-lane value in a register as-is (the compiler may not re-derive it from other values)
 #define HP3D_OPAQUE_V(x) asm volatile("" : "+v"(x))
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 // true the first time it is called for (this call site's flag array, current device): kernel function attributes
 // (dynamic LDS size) are per device, and one process may hold contexts on several devices
 static inline bool hp3d_first_use_on_device(bool (&done)[64]) {
@@ -95,12 +123,24 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
+// 8 B per lane (same addressing / range check)
+#define HP3D_BUFFER_LOAD8(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 0))
+// 16 B per lane at agent scope (sc1): the consuming side of an in-launch hand-off whose payload was stored write-through
+#define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 16))
 // 4 B per lane from (rsrc base + per-lane voff + scalar soff); out-of-range offsets read 0
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) \
     __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32((rsrc), (voff), (soff), 0))
 // 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
+// the same store written through to memory (sc1): payload of an in-launch hand-off to a workgroup on another XCD -- no
+// L2 write-back fence needed afterwards (cdna_hip_programming.md Guideline 16, R1)
+#define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 16)
+#define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, (val4)), (rsrc), (voff), (soff), 16)
 // 2 B per lane (a half); same addressing / range check
 #define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (hp3d_f16)(half_val)), (rsrc), (voff), (soff), 0)
@@ -112,7 +152,11 @@ typedef int hp3d_rsrc_t;
 #define HP3D_MAKE_RSRC(ptr, bytes) 0
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
+#define HP3D_BUFFER_LOAD8(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
+#define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) ((void)(rsrc), (void)(half_val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), 0.f)
@@ -178,6 +222,10 @@ int conv_first_launch(const ConvParams& p, hipStream_t s);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,
                        int pool, int* ksplit);
 size_t wino_packed_floats(int k, int cin_pad, int cout_pad);
+// the same transform on two workgroups per CU (conv_wino2.hip): v_mfma_f32_16x16x4_f32, 32 tiles x 64 couts x 16-channel steps
+void wino2_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
+int conv_wino2_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit);
+int conv_wino2_launch(const ConvParams& p, int pool, hipStream_t s);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
 // debug cross-check (one thread per output element, obviously-correct loops)

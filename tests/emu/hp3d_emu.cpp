@@ -121,6 +121,25 @@ f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c) {
     return c;
 }
 
+f32x4 hp3d_emu_mfma_16x16x4(float a, float b, f32x4 c) {
+    const unsigned tid = g_blk.cur->tid;
+    WaveX& w = g_blk.waves[tid >> 6];
+    const int lane = tid & 63, slot = w.gen & 1;
+    w.a[slot][lane] = a;
+    w.b[slot][lane] = b;
+    wave_rendezvous(w, 64);
+    // v_mfma_f32_16x16x4_f32: A[i][k] in lane i+16k, B[k][j] in lane j+16k,
+    // D reg r of lane l: col = l&15, row = 4*(l>>4) + r; k-ordered fmaf chain.
+    const int col = lane & 15, hi = lane >> 4;
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * hi + r;
+        float d = c[r];
+        for (int k = 0; k < 4; ++k) d = fmaf(w.a[slot][row + 16 * k], w.b[slot][col + 16 * k], d);
+        c[r] = d;
+    }
+    return c;
+}
+
 f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c) {
     const unsigned tid = g_blk.cur->tid;
     WaveX& w = g_blk.waves[tid >> 6];

@@ -56,6 +56,10 @@ static inline int hp3d_num_cus() { return 3; }     // small on purpose: persiste
 #define HP3D_READFIRSTLANE(x) (x)
 #define HP3D_OPAQUE_SGPR(x) (x)
 #define HP3D_WAIT_VMCNT0() ((void)0)
+// workgroups run one after another on the interpreter: the hand-off protocol reduces to its arithmetic
+#define HP3D_ACQUIRE_AGENT() ((void)0)
+#define HP3D_TICKET_AGENT(ptr) ((*(ptr))++)
+#define HP3D_STORE_RELAXED_AGENT(ptr, v) (*(ptr) = (v))
 struct hp3d_rsrc_t { const char* base; unsigned bytes; };
 #define HP3D_MAKE_RSRC(ptr, bytes) hp3d_rsrc_t{(const char*)(ptr), (unsigned)(bytes)}
 static inline void hp3d_emu_buffer_lds16(hp3d_rsrc_t r, float* lds_wave_base, unsigned off, int lane) {
@@ -70,16 +74,24 @@ static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
     return v;
 }
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     float v = 0.f;
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy(&v, r.base + voff + soff, 4);
     return v;
 }
 #define HP3D_BUFFER_LOAD4(rsrc, voff, soff) hp3d_emu_buffer_load4((rsrc), (unsigned)(voff), (unsigned)(soff))
+static inline f32x2 hp3d_emu_buffer_load8(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
+    f32x2 v = {0.f, 0.f};
+    if (voff < r.bytes && voff + soff + 8u <= r.bytes) memcpy(&v, r.base + voff + soff, 8);
+    return v;
+}
+#define HP3D_BUFFER_LOAD8(rsrc, voff, soff) hp3d_emu_buffer_load8((rsrc), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store2(hp3d_rsrc_t r, hp3d_f16 v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 2u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 2);
 }
@@ -88,6 +100,7 @@ static inline void hp3d_emu_buffer_store16(hp3d_rsrc_t r, f32x4 v, unsigned voff
     if (voff < r.bytes && voff + soff + 16u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 16);
 }
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) hp3d_emu_buffer_store16((rsrc), (val4), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) hp3d_emu_buffer_store16((rsrc), (val4), (unsigned)(voff), (unsigned)(soff))
 #define HP3D_GLDS16(gptr, lds_wave_base, lane) memcpy((float*)(lds_wave_base) + (lane) * 4, (gptr), 16)
 extern float* hp3d_emu_smem;
 #define HP3D_DYN_SMEM(name) float* name = hp3d_emu_smem
@@ -107,6 +120,8 @@ void hp3d_emu_syncthreads();
 #define __syncthreads hp3d_emu_syncthreads
 f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
 #define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))
+f32x4 hp3d_emu_mfma_16x16x4(float a, float b, f32x4 c);
+#define HP3D_MFMA_16x16x4(a, b, c) hp3d_emu_mfma_16x16x4((a), (b), (c))
 f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
 #define HP3D_MFMA_32x32x16_F16(a, b, c) hp3d_emu_mfma_32x32x16_f16((a), (b), (c))
 // skip must be uniform over the wave (every fiber takes the same branch, so the collective MFMA stays collective)
@@ -114,6 +129,14 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
     do {                                                                                           \
         if (!(skip))                                                                               \
             for (int _e = 0; _e < 4; ++_e) (acc) = hp3d_emu_mfma_32x32x2((a4)[_e], (b4)[_e], (acc)); \
+    } while (0)
+#define HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, skip)                      \
+    do {                                                                          \
+        if (!(skip))                                                              \
+            for (int _e = 0; _e < 4; ++_e) {                                      \
+                (acc0) = hp3d_emu_mfma_16x16x4((a0)[_e], (b4)[_e], (acc0));       \
+                (acc1) = hp3d_emu_mfma_16x16x4((a1)[_e], (b4)[_e], (acc1));       \
+            }                                                                     \
     } while (0)
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }

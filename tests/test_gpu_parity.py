@@ -101,6 +101,77 @@ def test_conv_winograd_vs_oracle(gpu_engine, case):
     assert not np.array_equal(y, yd), "the Winograd kernel did not run"
 
 
+W2_CASES = WINO_CASES + [(1, 32, 32, 256, 256, 0), (1, 32, 32, 512, 512, 0), (1, 128, 128, 64, 64, 1), (32, 160, 160, 64, 128, 0),
+            (1, 64, 64, 128, 128, 1), (1, 30, 40, 512, 512, 0), (2, 60, 80, 128, 256, 1)]
+
+
+@pytest.mark.parametrize("case", W2_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_conv_winograd_two_workgroups_per_cu_vs_oracle(gpu_engine, case):
+    """conv_wino2.hip (option wino2 = 1: F(2x2,3x3) on v_mfma_f32_16x16x4_f32, two workgroups per CU, 16-channel steps) on the
+    shapes of the conv_wino.hip test plus batch-1 PoseNet2D shapes (split channel steps) and the full-size Cin = 64 layers: same
+    tolerance against the float64-accumulating oracle, and the launch counter proves which kernel ran."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    big = B * H * W * Cout > 3e7          # the NumPy oracle needs a minute there: compare with conv_wino.hip instead (itself oracle-checked)
+    gpu_engine.set_option('wino2', '1')
+    try:
+        n0 = gpu_engine.counter('conv_wino2_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino2_launches') == n0 + 1
+        for _ in range(1 if big else 8):      # split launches reduce INSIDE the launch (agent-scope hand-off): a stale read would show here
+            y2 = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+            assert np.array_equal(y, y2), "not deterministic"
+    finally:
+        gpu_engine.set_option('wino2', 'auto')
+    if big:
+        gpu_engine.set_option('wino2', '0')
+        gpu_engine.set_option('conv_impl', 'winograd')
+        try:
+            r = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        finally:
+            gpu_engine.set_option('conv_impl', 'mfma')
+            gpu_engine.set_option('wino2', 'auto')
+    else:
+        r = _conv_ref(x, w, b, 1, True, pool)
+    err = np.abs(y - r).max()
+    print("conv_wino2 %s max|err| %.3e" % (case, err))
+    assert y.shape == r.shape and err < 5e-5
+
+
+@pytest.mark.parametrize("case", [(1, 32, 32, 160, 128), (4, 32, 32, 128, 128), (32, 32, 32, 128, 128)], ids=lambda c: "B%d_%dx%d_%d-%d" % c)
+def test_conv_winograd_two_workgroups_per_cu_7x7(gpu_engine, case):
+    """7x7 layers of the PoseNet2D refinement units on conv_wino2.hip (nine 3x3 blocks, shifted windows; split channel steps at
+    small batches)."""
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    gpu_engine.set_option('wino2', '1')
+    try:
+        n0 = gpu_engine.counter('conv_wino2_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, False)
+        assert gpu_engine.counter('conv_wino2_launches') == n0 + 1
+    finally:
+        gpu_engine.set_option('wino2', 'auto')
+    if B <= 4:
+        r = _conv_ref(x, w, b, 1, True, 0)
+    else:
+        gpu_engine.set_option('wino2', '0')
+        gpu_engine.set_option('conv_impl', 'winograd')
+        try:
+            r = gpu_engine.conv2d(x, w, b, 1, True, False)
+        finally:
+            gpu_engine.set_option('conv_impl', 'mfma')
+            gpu_engine.set_option('wino2', 'auto')
+    err = np.abs(y - r).max()
+    print("conv_wino2 7x7 %s max|err| %.3e" % (case, err))
+    assert err < 5e-5
+
+
 def test_conv_mfma_vs_naive_kernel(gpu_engine):
     """Same op through the obviously-correct one-thread-per-output kernel (debug path)."""
     rng = np.random.default_rng(7)
@@ -382,16 +453,30 @@ def test_full_pipeline_batch32_winograd_active(net, synth_weights):
     assert any(k.startswith('conv_wino') for k in kernels), kernels
     ev = EvalUtil()
     worst = dict(scoremap=0.0, kpmap=0.0, coord3d=0.0)
+    undecidable = []
     for i in range(32):
         taps = {}
         ref = N.inference(synth_weights, img[i:i + 1], hs[i:i + 1], True, acc=np.float64 if i in (0, 17) else np.float32, taps=taps)
-        assert np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0]), "image %d: hand mask differs" % i
-        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2]), i
         worst['scoremap'] = max(worst['scoremap'], float(np.abs(o['scoremap'][i:i + 1] - ref[0]).max()))
+        # the mask stage is exact on the engine's own score map ...
+        m = G.single_obj_scoremap(o['scoremap'][i:i + 1], early_exit=True)
+        cen, _, best = G.calc_center_bb(m)
+        assert np.array_equal(o['mask'][i], m[0, :, :, 0]), "image %d: mask growth differs from the oracle's on the same score map" % i
+        assert np.array_equal(o['center'][i:i + 1], cen) and np.array_equal(o['scale'][i:i + 1], G.scale_from_crop_size(best, 256)), i
+        # ... and equals the oracle's mask unless a pixel's fg probability sits within float32 rounding of 1/2 (random-weight
+        # logits do that on about one image in thirty; which way it rounds then depends on the summation order of the kernel)
+        if not np.array_equal(o['mask'][i], taps['hand_mask'][0, :, :, 0]):
+            fg, _ = G.fg_and_detmap(ref[0])
+            assert np.abs(fg - 0.5).min() < 1e-6, "image %d: hand mask differs although no pixel is near the rounding threshold" % i
+            undecidable.append(i)
+            continue
+        assert np.array_equal(o['center'][i:i + 1], ref[3]) and np.array_equal(o['scale'][i:i + 1], ref[2]), i
         worst['kpmap'] = max(worst['kpmap'], float(np.abs(o['kpmap'][i:i + 1] - ref[4]).max()))
         worst['coord3d'] = max(worst['coord3d'], float(np.abs(o['coord3d'][i:i + 1] - ref[5]).max()))
         ev.feed(ref[5][0], np.ones(21), o['coord3d'][i])
-    print("B=32 320x320, all 32 images vs oracle: worst %s, mean EPE %.3e" % (worst, ev.get_measures(0.0, 0.05, 20)[0]))
+    print("B=32 320x320, all 32 images vs oracle: worst %s, mean EPE %.3e, images with a knife-edge mask pixel: %s"
+          % (worst, ev.get_measures(0.0, 0.05, 20)[0], undecidable))
+    assert len(undecidable) <= 2
     assert worst['scoremap'] < TOL_HEATMAP and worst['kpmap'] < TOL_HEATMAP and worst['coord3d'] < TOL_KP3D
     net.engine.set_option('conv_impl', 'direct')
     try:

@@ -2,6 +2,7 @@
 // Host code only (the kernels live in conv_mfma.hip / glue.hip).  See include/hp3d.h for the
 // reference interfaces each entry point replaces.
 #include "hp3d_common.h"
+#include "lift_fused.h"
 #include "../../include/hp3d.h"
 
 #include <cmath>
@@ -50,6 +51,8 @@ struct ConvL {
     size_t w_off, b_off;   // offsets into the blob (floats)
     size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
     size_t ww2_off = 0;    // the same filters in conv_wino2.hip's fragment order (two workgroups per CU), 0 = none
+    size_t raw_off = 0;    // lifting nets only: [Cout/64][cin4][tap][64] for lift_fused.hip (one contiguous weight stream per wave), 0 = none
+    int cin4 = 0;
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
     size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
     int net;
@@ -87,6 +90,11 @@ struct Tables {
             blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
             l.ww2_off = blob_floats;
             blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
+        }
+        if (net == NET_PRIOR || net == NET_VP) {
+            l.cin4 = (cin + 15) / 16 * 16;          // four waves x whole channel quads
+            l.raw_off = blob_floats;
+            blob_floats += (size_t)9 * l.cin4 * ((cout + 63) / 64 * 64);
         }
         if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
             l.cin_pad16 = (l.mode == 1) ? 64 : (l.mode == 2) ? 192 : (cin + 63) / 64 * 64;
@@ -255,6 +263,9 @@ struct hp3d_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int use_h16 = 1;           // half-precision 3x3 trunk layers on conv_h16.hip (option "f16_impl" = "h16" | "mfma")
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
+    int use_lift_fused = -1;   // the lifting stage as one launch (lift_fused.hip): -1 auto (B <= 4), 0 never, 1 always (option "lift_fused")
+    unsigned* d_liftbar = nullptr;
+    long lift_fused_launches = 0;
     bool two_streams_live = false;   // set while a whole-path call runs its two halves on two streams (kernel choice: wino2_auto)
     int use_wino2 = -1;        // conv_wino2.hip (two workgroups per CU): -1 auto (short reductions, under-filled launches), 0 never, 1 wherever eligible (option "wino2")
     int use_graph = 0;
@@ -797,10 +808,58 @@ int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, floa
 }
 
 // _inference_pose3d (nets/ColorHandPose3DNetwork.py:221-247)
+// The same two towers as ONE launch (lift_fused.hip): small batches, where 24 dependent launches of ~13 us are the cost
+int run_lift_fused(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int bottleneck, int do_rot) {
+    LiftFusedParams p;
+    memset(&p, 0, sizeof p);
+    p.sm = sm32; p.sm_cs = 32; p.hs = hs; p.B = B; p.towers = do_rot ? 3 : 1;
+    char nm[64];
+    for (int t = 0; t < 2; ++t)
+        for (int i = 0; i < 6; ++i) {
+            snprintf(nm, sizeof nm, t == 0 ? "PosePrior/conv_pose_%d_%d" : "ViewpointNet/conv_vp_%d_%d", i / 2, i % 2 + 1);
+            const ConvL& l = CL(ctx, nm);
+            p.w[t * 6 + i] = ctx->blob + l.raw_off; p.b[t * 6 + i] = ctx->blob + l.b_off;
+            p.cin[t * 6 + i] = l.cin4; p.cout[t * 6 + i] = l.cout;
+        }
+    const char* fcn[6] = {"PosePrior/fc_rel0", "PosePrior/fc_rel1", bottleneck ? "PosePrior/fc_xyz#bn" : "PosePrior/fc_xyz",
+                          "ViewpointNet/fc_vp0", "ViewpointNet/fc_vp1", "ViewpointNet/fc_vp_u"};
+    for (int f = 0; f < 6; ++f) {
+        const FcL& l = FL(ctx, fcn[f]);
+        p.fw[f] = ctx->blob + l.w_off; p.fb[f] = ctx->blob + l.b_off; p.fc_in[f] = l.cin; p.fc_out[f] = l.cout;
+    }
+    if (bottleneck) {
+        const FcL& l = FL(ctx, "PosePrior/fc_bottleneck");
+        p.bn_w = ctx->blob + l.w_off; p.bn_b = ctx->blob + l.b_off;
+        p.fc_in[2] = 512;             // the last stage reads fc_rel1's 512 outputs; the 30-wide layer sits inside it
+    }
+    const size_t act = (size_t)B * 32 * 32 * 64;
+    for (int t = 0; t < 2; ++t)
+        for (int q = 0; q < 2; ++q) p.act[t][q] = ctx->bufA + (size_t)(t * 2 + q) * act;
+    float* fp = ctx->d_fcpart;
+    p.fcp[0][0] = fp; fp += (size_t)9 * B * 512;
+    p.fcp[0][1] = fp; fp += (size_t)2 * B * 512;
+    p.fcp[1][0] = fp; fp += (size_t)17 * B * 256;
+    p.fcp[1][1] = fp;
+    p.out[0] = ctx->d_can; p.out[1] = ctx->d_u;
+    if (!ctx->d_liftbar) CHK(dev_realloc(ctx, &ctx->d_liftbar, 4));
+    p.bar = ctx->d_liftbar;
+    ProfScope ps(ctx, "PosePrior+ViewpointNet", "lift_fused", 2.0 * B * (45.0e6 / 2 + 157.0e6 / 2 * (do_rot ? 1 : 0) + 2.7e6 / 2), 4.0 * 15.5e6);
+    if (lift_fused_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_HIP, "lift_fused launch failed");
+    ++ctx->lift_fused_launches;
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant) {
-    CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
     const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
-    if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
+    const bool fused = !ctx->conv_naive && (ctx->use_lift_fused == 1 || (ctx->use_lift_fused < 0 && B <= 4)) &&
+                       (size_t)4 * B * 32 * 32 * 64 <= ctx->act_floats;
+    if (fused) {
+        CHK(run_lift_fused(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, do_rot));
+    } else {
+        CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
+        if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
+    }
     if (variant == HP3D_VARIANT_LOCAL)     // bone_rel_trafo_inv (nets/PosePriorNetwork.py:70-75)
         bone_rel_inv_launch(ctx->d_can, B, ctx->d_coord, ctx->stream);
     else
@@ -989,7 +1048,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1225,6 +1284,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
 #endif
     if (ctx->comm) hp3d_comm_destroy(ctx);
     if (ctx->d_seed) hipFree(ctx->d_seed);
+    if (ctx->d_liftbar) hipFree(ctx->d_liftbar);
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
     if (ctx->d_u8) hipFree(ctx->d_u8);
@@ -1326,6 +1386,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
@@ -1414,6 +1475,11 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
         const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, l.name + "/biases", &b) == 0;
         mark(l.net, ok);
         if (ok) pack_conv(l, w->data.data(), b->data.data(), host.data());
+        if (ok && l.raw_off)          // lift_fused.hip: [cout block of 64][cin4][tap][64], zero rows / columns as padding
+            for (int t = 0; t < 9; ++t)
+                for (int c = 0; c < l.cin; ++c)
+                    for (int co = 0; co < l.cout; ++co)
+                        host[l.raw_off + (((size_t)(co >> 6) * l.cin4 + c) * 9 + t) * 64 + (co & 63)] = w->data[((size_t)t * l.cin + c) * l.cout + co];
         if (ok && l.ww_off) {      // U = G g G^T in the Winograd kernel's fragment order
             std::vector<int> cmap(l.cin_pad, -1);
             for (int e = 0; e < l.cin_pad; ++e) {
@@ -1966,6 +2032,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);

@@ -318,3 +318,60 @@ def test_argmax_ordering_of_signed_zeros_and_nans_is_numpys(emu_engine):
     z[0, 2, 2, 1] = -0.0
     up = T.resize_bilinear_legacy(z, 32, 32)
     assert np.array_equal(emu_engine.detect_keypoints(z, (32, 32))[0], PG.detect_keypoints(up[0]))
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 8, 12, 96, 128, 1, 3),
+                                  (1, 17, 21, 32, 64, 0, 3), (1, 12, 14, 32, 128, 0, 7), (2, 9, 11, 40, 64, 0, 7)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d_k%d" % c)
+def test_winograd_two_workgroups_per_cu_kernel_on_interpreter(emu_engine, case):
+    """conv_wino2.hip (option wino2 = 1) on the interpreter: v_mfma_f32_16x16x4_f32 lane maps, the swizzled V rows, pair loader,
+    weight packing [plane][step][Cout/16][q][n][e], 3x3 and 7x7 (nine blocks, zero planes skipped), fused pool, ragged tile
+    grids, and the channel split (the interpreter's "chip" has 6 slots, so the small cases split)."""
+    B, H, W, Cin, Cout, pool, k = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('wino2', '1')
+    try:
+        for sk in ('0', '1'):
+            emu_engine.set_option('wino_splitk', sk)
+            n0 = emu_engine.counter('conv_wino2_launches')
+            y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+            assert emu_engine.counter('conv_wino2_launches') == n0 + 1
+            assert np.abs(y - r).max() < 1e-5, sk
+    finally:
+        emu_engine.set_option('wino2', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+
+
+def test_lift_fused_one_launch_lifting_stage_on_interpreter(emu_engine, synth_weights):
+    """lift_fused.hip (phases as launches on the interpreter): PosePrior + ViewpointNet conv / fc chains, stride-2 SAME padding,
+    hand-side concat, K-slice partial sums finished by the consumer, bottleneck variant -- against the oracle and the layer-by-layer
+    kernels."""
+    rng = np.random.default_rng(1)
+    sm = (rng.standard_normal((3, 32, 32, 21)) * 0.3).astype(np.float32)
+    hs = synth.hand_sides(3)
+    emu_engine.load_weight_dict({k: v for k, v in synth_weights.items() if k.startswith(('PosePrior', 'ViewpointNet'))})
+    emu_engine.finalize_weights()
+    ref = N.pose3d(synth_weights, sm, hs, acc=np.float64)
+    try:
+        for mode in ('0', '1'):
+            emu_engine.set_option('lift_fused', mode)
+            n0 = emu_engine.counter('lift_fused_launches')
+            out = emu_engine.pose3d(sm, hs)
+            assert emu_engine.counter('lift_fused_launches') - n0 == int(mode)
+            for a, b in zip(out, ref):
+                assert np.abs(a - b).max() < 1e-5, mode
+        wb = synth.make_weights(bottleneck=True)
+        emu_engine.load_weight_dict({k: v for k, v in wb.items() if k.startswith('PosePrior')})
+        emu_engine.finalize_weights()
+        sm256 = synth.lifting_scoremaps(5, 2)
+        r = N.poseprior_network(wb, 'bottleneck', sm256, synth.hand_sides(2))
+        o = emu_engine.poseprior('bottleneck', sm256, synth.hand_sides(2))
+        assert np.abs(o[0] - r[0]).max() < 1e-5
+    finally:
+        emu_engine.set_option('lift_fused', 'auto')

@@ -369,6 +369,59 @@ def test_pose3d_and_poseprior_variants(gpu_engine, synth_weights):
     gpu_engine.finalize_weights()
 
 
+def test_lift_fused_one_launch_lifting_stage(gpu_engine, synth_weights):
+    """lift_fused.hip: PosePrior + ViewpointNet (12 convolutions, 6 fully connected layers) as ONE launch with grid barriers
+    between the layers -- against the oracle (float64 accumulation), against the layer-by-layer kernels, for every batch size the
+    auto policy sends there (B <= 4) and a larger forced one, all variants; repeated calls must be bit-identical (a stale read
+    across a grid barrier would show as a difference between calls)."""
+    from hand3d_amd import PosePriorNetwork
+    rng = np.random.default_rng(18)
+    for B in (1, 3, 4, 9):
+        sm = (rng.standard_normal((B, 32, 32, 21)) * 0.3).astype(np.float32)
+        hs = synth.hand_sides(B)
+        ref = N.pose3d(synth_weights, sm, hs, acc=np.float64)
+        outs = {}
+        for mode in ('0', '1'):
+            gpu_engine.set_option('lift_fused', mode)
+            n0 = gpu_engine.counter('lift_fused_launches')
+            outs[mode] = gpu_engine.pose3d(sm, hs)
+            assert gpu_engine.counter('lift_fused_launches') - n0 == int(mode)
+            for a, b in zip(outs[mode], ref):
+                assert np.abs(a - b).max() < TOL_KP3D, (B, mode, float(np.abs(a - b).max()))
+        for _ in range(10):
+            again = gpu_engine.pose3d(sm, hs)
+            for a, b in zip(again, outs['1']):
+                assert np.array_equal(a, b), "the one-launch lifting stage is not deterministic"
+        print("lift_fused B=%d: vs oracle %s, vs layer-by-layer %s" % (B, ['%.1e' % np.abs(a - b).max() for a, b in zip(outs['1'], ref)],
+                                                                       ['%.1e' % np.abs(a - b).max() for a, b in zip(outs['1'], outs['0'])]))
+    gpu_engine.set_option('lift_fused', '1')
+    try:
+        sm256 = np.maximum(rng.standard_normal((3, 256, 256, 21)).astype(np.float32), 0) * 0.2
+        hs = synth.hand_sides(3)
+        wprior = {k: v for k, v in synth_weights.items() if k.startswith(('PosePrior', 'ViewpointNet'))}
+        for variant, ref_variant, wts in (('proposed', 'proposed', None), ('direct', 'direct', None), ('local', 'local', None), ('bottleneck', 'bottleneck', 'bn')):
+            w = synth_weights
+            if wts == 'bn':
+                w = synth.make_weights(bottleneck=True)
+                net = PosePriorNetwork(variant, engine=gpu_engine)
+                net.init_from_dict({k: v for k, v in w.items() if k.startswith('PosePrior')})
+            else:
+                net = PosePriorNetwork(variant, engine=gpu_engine)
+                net.init_from_dict(wprior)
+            n0 = gpu_engine.counter('lift_fused_launches')
+            got = net.inference(sm256, hs, True)
+            assert gpu_engine.counter('lift_fused_launches') == n0 + 1
+            exp = N.poseprior_network(w, ref_variant, sm256, hs, acc=np.float64)
+            for a, b in zip(got, exp):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    assert np.abs(a - b).max() < TOL_KP3D, variant
+    finally:
+        gpu_engine.set_option('lift_fused', 'auto')
+        gpu_engine.load_weight_dict(synth_weights)
+        gpu_engine.finalize_weights()
+
+
 def _full_parity(net, weights, img, hs):
     o = net.engine.infer_full(img, hs, want_mask=True)
     taps = {}

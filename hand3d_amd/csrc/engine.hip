@@ -462,7 +462,7 @@ void same_pad(int in, int k, int stride, int* out, int* before) {
 // input-transform work per MFMA).  `old_nt` / `old_ks`: conv_wino_eligible's answer for the same layer (0: it would not run).
 bool wino2_auto(int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int old_nt, int old_ks, int ks2, bool two_streams) {
     if ((long)B * Ho * Wo < 512) return false;              // 16 x 16 maps and below: one direct launch beats split + reduce
-    if (!old_nt) return true;
+    if (!old_nt) return Ho * Wo >= 900 && cin_pad >= 64;      // trunk layers conv_wino.hip cannot fill; the lifting nets' 16 x 16 / 8 x 8 maps stay direct
     const double cus = hp3d_num_cus(), reduce_cost = 0.7, c2 = 1.07;
     const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
     const int nsub = k == 7 ? 9 : 1;
@@ -2047,7 +2047,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {
         int st = 1;                                                        // glue: softmax / mask / crop
         if (r.name.rfind("HandSegNet/", 0) == 0) st = 0;
         else if (r.name.rfind("PoseNet2D/", 0) == 0 || r.name == "kp_upsample") st = 2;
-        else if (r.name.rfind("PosePrior/", 0) == 0 || r.name.rfind("ViewpointNet/", 0) == 0 || r.name == "lift_epilogue" ||
+        else if (r.name.rfind("PosePrior", 0) == 0 || r.name.rfind("ViewpointNet/", 0) == 0 || r.name == "lift_epilogue" ||
                  r.name == "concat_handside" || r.name.rfind("fc", 0) == 0) st = 3;
         acc[st] += ms;
         acc[4] += ms;

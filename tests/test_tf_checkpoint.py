@@ -1,6 +1,8 @@
 """TF V2 checkpoint reader + load_weights_from_snapshot selection semantics
 (reference utils/general.py:614-651).  No TensorFlow here: the format code is exercised by round trips, corruption
 checks and the published crc32c test vectors."""
+import struct
+
 import numpy as np
 import pytest
 
@@ -97,3 +99,73 @@ def test_snapshot_feeds_the_engine_loader(tmp_path, emu_engine, synth_weights):
     net = ColorHandPose3DNetwork(engine=emu_engine)
     net.init_from_dict(w)
     assert emu_engine.nets_mask() & 15 == 15
+
+
+def _crc32c_bitwise(data):
+    """An independent CRC-32C (reflected polynomial 0x82F63B78, bit by bit): not the module's table / native code."""
+    crc = 0xFFFFFFFF
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+    return crc ^ 0xFFFFFFFF
+
+
+def _masked(data):
+    c = _crc32c_bitwise(data)
+    return struct.pack('<I', ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF)
+
+
+def test_reader_on_a_bundle_assembled_by_hand(tmp_path):
+    """A two-tensor V2 checkpoint written out BYTE BY BYTE from the published layout (leveldb table format + BundleHeaderProto /
+    BundleEntryProto of tensorflow/core/protobuf/tensor_bundle.proto), not by write_bundle: the reader is not only checked
+    against its own writer.  Zero-valued proto fields (shard_id 0, offset 0) are omitted as proto3 writers do; the second key
+    is prefix-compressed against the first ("a/" shared); checksums come from an independent bit-by-bit CRC-32C."""
+    assert _crc32c_bitwise(b'123456789') == 0xE3069283
+    biases = struct.pack('<2f', 1.0, -2.0)                 # "a/biases"  float32 [2]    at offset 0
+    weights = struct.pack('<2f', 0.5, 3.0)                 # "a/weights" float32 [1, 2] at offset 8
+    data = biases + weights
+    header = bytes([0x08, 0x01,                            # BundleHeaderProto.num_shards = 1
+                    0x10, 0x00,                            # .endianness = LITTLE
+                    0x1A, 0x02, 0x08, 0x01])               # .version { producer: 1 }
+    e_b = bytes([0x08, 0x01,                               # BundleEntryProto.dtype = DT_FLOAT
+                 0x12, 0x04, 0x12, 0x02, 0x08, 0x02,       # .shape { dim { size: 2 } }
+                 0x28, 0x08,                               # .size = 8            (shard_id = 0 and offset = 0: omitted)
+                 0x35]) + _masked(biases)                  # .crc32c (fixed32, masked)
+    e_w = bytes([0x08, 0x01,
+                 0x12, 0x08, 0x12, 0x02, 0x08, 0x01, 0x12, 0x02, 0x08, 0x02,      # .shape { dim { size: 1 } dim { size: 2 } }
+                 0x20, 0x08,                               # .offset = 8
+                 0x28, 0x08,
+                 0x35]) + _masked(weights)
+    # data block: entries (shared, non_shared, value_len, key suffix, value), restart array [0], restart count 1
+    block = (bytes([0, 0, len(header)]) + header +
+             bytes([0, 8, len(e_b)]) + b'a/biases' + e_b +
+             bytes([2, 7, len(e_w)]) + b'weights' + e_w +
+             struct.pack('<II', 0, 1))
+    table = block + b'\x00' + _masked(block + b'\x00')               # compression type 0 + masked crc of (block + type)
+    meta = struct.pack('<II', 0, 1)                                   # empty metaindex block: one restart at 0
+    meta_off = len(table)
+    table += meta + b'\x00' + _masked(meta + b'\x00')
+    handle = bytes([0x00, len(block)])                                # BlockHandle of the data block: offset 0, size (both < 128)
+    assert len(block) < 128
+    index = bytes([0, len(b'a/weights'), len(handle)]) + b'a/weights' + handle + struct.pack('<II', 0, 1)
+    index_off = len(table)
+    table += index + b'\x00' + _masked(index + b'\x00')
+    footer = bytes([meta_off, len(meta), index_off, len(index)])      # two BlockHandles as varints (all < 128 here)
+    assert max(footer) < 128
+    table += footer + b'\x00' * (40 - len(footer)) + bytes.fromhex('57fb808b247547db')      # magic 0xdb4775248b80fb57, little endian
+    prefix = str(tmp_path / 'model-1')
+    open(prefix + '.index', 'wb').write(table)
+    open(prefix + '.data-00000-of-00001', 'wb').write(data)
+    got = C.read_bundle(prefix)
+    assert sorted(got) == ['a/biases', 'a/weights']
+    assert got['a/biases'].dtype == np.float32 and got['a/biases'].tolist() == [1.0, -2.0]
+    assert got['a/weights'].shape == (1, 2) and got['a/weights'].tolist() == [[0.5, 3.0]]
+    # and the writer produces a table the same reader accepts with identical content (two independent byte streams, one meaning)
+    back = C.read_bundle(C.write_bundle(str(tmp_path / 'w' / 'model-1'), got))
+    assert all(np.array_equal(back[k], got[k]) for k in got)
+    # a flipped payload bit is caught by the hand-computed checksum
+    bad = bytearray(data); bad[1] ^= 0x10
+    open(prefix + '.data-00000-of-00001', 'wb').write(bytes(bad))
+    with pytest.raises(ValueError):
+        C.read_bundle(prefix)

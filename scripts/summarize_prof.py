@@ -26,6 +26,10 @@ def _tree_id():
 def family(name):
     if 'conv_wino_kernel' in name:
         return 'conv_wino'
+    if 'conv_wino2_kernel' in name:
+        return 'conv_wino2'
+    if 'lift_fused_kernel' in name:
+        return 'lift_fused'
     if 'conv_mfma_kernel' in name:
         return 'conv_mfma'
     if 'conv_first_kernel' in name:

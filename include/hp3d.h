@@ -72,9 +72,16 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            can run it.  conv_wino.hip gives one wave a whole SIMD (256 accumulators, 32-channel steps, 128-cout
  *                            items: long reductions); conv_wino2.hip runs two workgroups per CU on v_mfma_f32_16x16x4_f32 (128
  *                            accumulators, 16-channel steps, 64-cout items), so one item's epilogue / waits are the other's MFMA
- *                            time and a launch has four times as many, four times finer work items.  auto = conv_wino2 for
- *                            Cin <= 64 and for launches that under-fill conv_wino's grid (small batches); "1" = wherever the
- *                            shape allows (tests); "0" = never.  Same arithmetic: results agree to accumulation order;
+ *                            time and a launch has four times as many, four times finer work items.  auto = a per-layer cost
+ *                            model of both kernels' rounds of work items (engine.hip:wino2_auto): in practice conv_wino2 for
+ *                            launches that under-fill or badly quantise conv_wino's grid (small batches), conv_wino for B = 32;
+ *                            "1" = wherever the shape allows (tests); "0" = never.  Same arithmetic: results agree to
+ *                            accumulation order;
+ *          "lift_fused"   = "auto" (default) | "0" | "1": PosePrior + ViewpointNet + the lifting epilogue
+ *                            (ColorHandPose3DNetwork.py:221-334) as ONE persistent launch with grid barriers (lift_fused.hip)
+ *                            instead of 24 launches.  auto = for at most 4 images per call (the stage is latency-bound there:
+ *                            0.33 -> 0.14 ms at B = 1); "1" = always (tests; needs the whole grid resident, which the launcher
+ *                            checks); "0" = never.  Results agree to accumulation order (2-5e-7);
  *          "micro_batch"  = "N" | "auto": whole-path calls (hp3d_infer_full*) run as consecutive chunks of at most N
  *                            images ("0" = never split; default "auto" = at most 32 in float32 mode -- fewer when H x W x 64 floats x N
  *                            would pass 2^31 bytes, e.g. 480x640: balanced chunks of <= 27 -- and no split with f16 trunks).
@@ -223,7 +230,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
 /* Executor counters: "graph_captures" / "graph_replays" = hipGraphs instantiated / launched since hp3d_create (option
  * "graph" = "1"; a replay happens only with per-launch profiling off); "conv_h16_launches" = half-precision trunk
  * layers that ran on conv_h16.hip (option "f16_impl"); "conv_wino2_launches" = float32 layers that ran on conv_wino2.hip (option
- * "wino2"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
+ * "wino2"); "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);
 

@@ -330,7 +330,9 @@ def main():
             # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
             # nine 3x3 blocks of its zero-extended 9x9 form, minus the structurally zero planes of the edge blocks (round 3):
             # (4*16 + 4*12 + 9) = 121 plane products per 4*49
-            exe = (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k == 'conv_wino' else 1.0
+            # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks: 324/784
+            exe = ((324.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if kern.startswith('conv_wino4') else
+                   (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0)) if k == 'conv_wino' else 1.0
             f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
             f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
         total_ms = max(sum(v[0] for v in fam.values()), 1e-9)
@@ -361,8 +363,9 @@ def main():
             roof["note"] = ("half-precision 3x3 trunk kernel (all instantiations: 1 / 2 / 4 cout blocks per wave, pooled, fused conv1_1 + conv1_2); "
                             "direct form, so executed = algorithmic; the fused launches count conv1_1's FLOPs too")
         if dom == 'conv_wino':
-            roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
-                            "blocks without their structurally zero planes: 121/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
+            roof["note"] = ("float32 Winograd: F(2x2,3x3) executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
+                            "blocks without their structurally zero planes: 121/196), F(4x4,3x3) (kernels named conv_wino4_*) 36/144 "
+                            "(7x7: 324/784); frac is the executed matrix-core rate over the dense f32 MFMA peak")
         workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step" % (H, W, B)) \
             if a.workload == 'full' else ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B)
         roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str, a.dtype)

@@ -1,0 +1,420 @@
+// conv_wino4.hip -- Winograd F(4x4, 3x3) on the f32 matrix cores (round 3).
+//
+// Same call sites as conv_wino.hip / conv_wino2.hip (NetworkOps.conv_relu + max_pool, utils/general.py:36-65; the 3x3 /
+// stride-1 layers and the 7x7 layers of PoseNet2D, nets/ColorHandPose3DNetwork.py:170-219, as nine 3x3 blocks), with the
+// larger Winograd tile: a 6x6 input window gives 4x4 outputs through 36 element-wise products per (cin, cout) -- 2.25
+// multiply-adds per output instead of 4 (F(2x2,3x3)) or 9 (direct).  Float32 throughout; the transforms now multiply by
+// 2, 4, 5, 8 and the transformed filters by 1/4 .. 1/24, which costs 3.5x the rounding error of F(2x2,3x3) END TO END on
+// PoseNet2D (heat-maps 4.7e-6 against a gate of 1e-3, profiles/r03_tuning_notes.md section 5) -- the executor takes this kernel
+// only where that was measured (option "wino4").
+//
+//   Y(4x4) = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          d: 6x6 window, g: 3x3 filter, points {0, +-1, +-2, inf}
+//
+// Machine shape: conv_wino2.hip's (v_mfma_f32_16x16x4_f32, a wave = 32 tiles x 16 couts, a workgroup = 32 tiles x 64
+// couts in 16-channel steps, K order permuted so that A and B are one 16-byte access per four MFMAs, weights global ->
+// VGPR in fragment order) with 36 planes instead of 16:
+//   * 36 planes x 2 tile halves x 4 = 288 accumulators per lane -> one wave per SIMD (__launch_bounds__(256, 1): 512
+//     registers per lane, the compiler splits the accumulators over AGPRs and VGPRs);
+//   * V = B^T d B double buffered in LDS: 2 x 36 planes x 32 tiles x 16 channels = 147 KB;
+//   * loader thread = (tile, channel pair): 36 window loads of 8 bytes; the offsets are 6 row + 6 column terms (a row /
+//     column outside the image carries a constant that pushes the sum out of the buffer's range: reads as 0) added at
+//     issue time, not 36 registers;
+//   * a tile is 16 output pixels: the fused 2x2 max-pool takes four maxima per tile; ragged image edges (Ho, Wo not a
+//     multiple of 4) drop rows / columns through out-of-range store offsets.
+#include "hp3d_common.h"
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace {
+
+constexpr int W4_TILES = 32;                       // Winograd tiles (4x4 outputs each) per item
+constexpr int W4_CK = 16;                          // channels per step
+constexpr int W4_COUTS = 64;                       // output channels per item (16 per wave)
+constexpr int W4_NP = 36;                          // planes
+constexpr int W4_PLANE_FLOATS = W4_TILES * W4_CK;  // one plane of one V buffer: 2 KB
+constexpr int W4_VBUF_FLOATS = W4_NP * W4_PLANE_FLOATS;
+constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4;     // 2 V buffers + two tile tables = 147968 B
+#ifndef HP3D_W4_RING
+#define HP3D_W4_RING 9
+#endif
+constexpr int W4_RING = HP3D_W4_RING;              // weight fragments in flight (planes); must divide 36
+static_assert(W4_NP % W4_RING == 0, "static ring slots need a ring that divides the plane count");
+constexpr int W4_HALF = 18;                        // planes reachable from one LDS base (16-bit immediate offsets)
+constexpr int W4_TRANSFORM_AT = 29;                // the plane under which the next step's windows are transformed
+
+// same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
+__device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }
+
+// B^T of F(4x4,3x3) applied to six values in place:
+//   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ void w4_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+    const f32x2 t0 = (4.f * x0 + x4) - 5.f * x2;
+    const f32x2 t5 = (4.f * x1 + x5) - 5.f * x3;
+    const f32x2 s12 = x1 + x2, d12 = x1 - x2, s34 = x3 + x4, d43 = x4 - x3, d31 = x3 - x1, d42 = x4 - x2;
+    x0 = t0;
+    x1 = s34 - 4.f * s12;
+    x2 = d43 + 4.f * d12;
+    x3 = d42 + 2.f * d31;
+    x4 = d42 - 2.f * d31;
+    x5 = t5;
+}
+// A^T of F(4x4,3x3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
+    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+    y0 = (m0 + s12) + s34;
+    y1 = d12 + 2.f * d34;
+    y2 = s12 + 4.f * s34;
+    y3 = (d12 + 8.f * d34) + m5;
+}
+
+template <bool POOL, int NSUB, bool SPLITK>
+HP3D_KERNEL2(256, 1)
+void conv_wino4_kernel(const ConvParams p) {
+    static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
+    HP3D_DYN_SMEM(V);
+    int* tinfo = (int*)(V + 2 * W4_VBUF_FLOATS);       // [parity][0..31] output offset of tile t (-1: none), [32..63] edge flags
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = HP3D_READFIRSTLANE(tid >> 6);
+    const int ln = lane & 15, lq = lane >> 4;          // MFMA column (cout / tile in block) and k slot
+
+    const int TXn = p.tiles_x, TYn = p.tiles_y, per_img = TXn * TYn;
+    const int tile_blocks = (p.B * per_img + W4_TILES - 1) / W4_TILES;
+    const int ncy = p.Cout / W4_COUTS;
+    const int per_split = tile_blocks * ncy;
+    const int nitems = per_split * (SPLITK ? p.ksplit : 1);
+    auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) {      // same flattened band order as conv_wino.hip
+        tb = id / per_img;
+        const int r = id - tb * per_img;
+        const int band = r / (4 * TXn), rem = r - band * 4 * TXn;
+        const int rows = min(4, TYn - 4 * band);
+        txx = rem / rows;
+        tyy = band * 4 + rem - txx * rows;
+    };
+    const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
+    // tile table.  Plain: offset of output (4 ty, 4 tx), flags = valid rows | valid columns << 4 (1..4 each).  Pooled: offset of
+    // pooled output (2 ty, 2 tx), flags = bit 0: column 2 tx + 1 exists, bit 1: row 2 ty + 1 exists.
+    auto table_write = [&](int tblock, int parity, int kz) {
+        if (tid < W4_TILES) {
+            int tb, tyy, txx;
+            tile_decode(tblock * W4_TILES + tid, tb, tyy, txx);
+            int off = -1, fl = 0;
+            if (tb < p.B) {
+                if (POOL) {
+                    if (2 * tyy < Hs && 2 * txx < Ws) {
+                        off = ((tb * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
+                        fl = (2 * txx + 1 < Ws ? 1 : 0) | (2 * tyy + 1 < Hs ? 2 : 0);
+                    }
+                } else {
+                    off = (((SPLITK ? kz * p.B + tb : tb) * Hs + 4 * tyy) * Ws + 4 * txx) * p.out_cs;
+                    fl = min(4, Hs - 4 * tyy) | (min(4, Ws - 4 * txx) << 4);
+                }
+            }
+            tinfo[parity * 2 * W4_TILES + tid] = off;
+            tinfo[parity * 2 * W4_TILES + W4_TILES + tid] = fl;
+        }
+    };
+
+    // ---- loader role: this thread transforms the 6x6 window of tile lt for channel pair lp ------------------------------
+    const int lt = tid >> 3, lp = tid & 7;
+    const int cs4 = p.in_cs * 4;
+    constexpr int OOR = (int)0x80000000;          // row outside the image / no such tile
+    constexpr int COL_OOR = 0x60000000;           // column outside the image: any row term + this is >= 2^30 > the buffer's extent
+    int ro[6], co[6];
+    int cb = 0, cty = 0, ctx_ = 0;                // NSUB = 9 only: tile coordinates stay live for the block shifts
+    auto window_offsets = [&](bool valid, int lb, int lty, int ltx, int sub) {
+        const int dy = NSUB == 1 ? 0 : 3 * (sub / 3) - 2, dx = NSUB == 1 ? 0 : 3 * (sub % 3) - 2;
+        const int wy0 = 4 * lty - 1 + dy, wx0 = 4 * ltx - 1 + dx;
+        const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lp * 8;
+        const bool tv = valid && lb < p.B;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * p.W * cs4 : OOR;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * cs4 : COL_OOR;
+    };
+    auto loader_setup = [&](int tblock, bool valid, int sub) {
+        int lb, lty, ltx;
+        tile_decode(tblock * W4_TILES + lt, lb, lty, ltx);
+        if (NSUB > 1) { cb = valid ? lb : p.B; cty = lty; ctx_ = ltx; }
+        window_offsets(valid, lb, lty, ltx, NSUB > 1 ? sub : 0);
+    };
+    auto loader_shift = [&](int sub) { window_offsets(true, cb, cty, ctx_, sub); };
+    const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
+    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
+
+    f32x2 d[36];
+    auto window_fetch = [&](int soff) {
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) d[r * 6 + c] = HP3D_BUFFER_LOAD8(irsrc, (int)((unsigned)ro[r] + (unsigned)co[c]), soff);
+    };
+    float* const Vw = V + lt * W4_CK + ((lp >> 1) ^ w4_swz(lt)) * 4 + (lp & 1) * 2;      // this thread's slot in plane 0 of buffer 0
+    auto transform_commit = [&](int buf) {
+        // B^T d B in place: along the window rows first (plane row a), then along the columns (plane column b) straight into LDS
+#pragma unroll
+        for (int c = 0; c < 6; ++c) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
+        float* Vq0 = Vw + buf * W4_VBUF_FLOATS;
+        float* Vq1 = Vq0 + W4_HALF * W4_PLANE_FLOATS;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                const int pl = a * 6 + b;
+                float* dst = pl < W4_HALF ? Vq0 + pl * W4_PLANE_FLOATS : Vq1 + (pl - W4_HALF) * W4_PLANE_FLOATS;
+                *(f32x2*)dst = d[pl];
+            }
+        }
+    };
+
+    // ---- MFMA role -------------------------------------------------------------------------------------------------------
+    // packed U: [plane 36][step (NSUB * Cin / 16)][Cout/16][q 4][n 16][e 4]: the fragment a wave needs for one (plane, step) is
+    // 1 KB, lane-linear: base = one scalar offset per (plane, step)
+    const int CO16 = p.Cout >> 4;
+    const int nsub_rt = NSUB == 1 ? 1 : p.nsub;
+    const int csteps = p.Cin / W4_CK;
+    const int nsteps = nsub_rt * csteps;
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(W4_NP * nsub_rt * p.Cin) * (unsigned)p.Cout * 4u);
+    const int step_stride_b = CO16 * 1024;
+    const int plane_stride_b = nsteps * step_stride_b;
+    auto soff_of = [&](int plane, int step) { return plane * plane_stride_b + step * step_stride_b; };
+
+    f32x4 M[W4_NP][2];     // [plane][tile half]: rows = tiles 16 m + 4 (lane >> 4) + r, column = cout (lane & 15)
+    f32x4 bq[W4_RING];
+    auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
+    const int va_lane = (ln * W4_CK + ((lq ^ w4_swz(ln)) * 4)) * 4;
+    int ab0 = 0, ab1 = 0;
+    f32x4 af[2][2];
+    auto a_fetch = [&](int set, int plane) {
+        const int base = plane < W4_HALF ? ab0 : ab1, pl = plane < W4_HALF ? plane : plane - W4_HALF;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) af[set][m] = *(const f32x4*)((const char*)V + base + (pl * W4_PLANE_FLOATS + m * 16 * W4_CK) * 4);
+    };
+
+    auto split_of = [&](int it, int& kz, int& cy_, int& tb_) {
+        kz = SPLITK ? it / per_split : 0;
+        const int r = SPLITK ? it - kz * per_split : it;
+        cy_ = r / tile_blocks;
+        tb_ = r - cy_ * tile_blocks;
+    };
+    auto first_step_of = [&](int kz) { return SPLITK ? HP3D_READFIRSTLANE((kz * nsteps) / p.ksplit) : 0; };
+    int item = blockIdx.x;
+    int kz, cy, tblock;
+    split_of(item, kz, cy, tblock);
+    int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
+    const int sub0 = (NSUB > 1 && SPLITK) ? HP3D_READFIRSTLANE(s0 / csteps) : 0;
+    loader_setup(tblock, true, sub0);
+    table_write(tblock, 0, kz);
+    int wvoff = (cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
+    window_fetch((s0 - sub0 * csteps) * (W4_CK * 4));
+#pragma unroll
+    for (int t = 0; t < W4_RING; ++t) b_fetch(t, wvoff, soff_of(t, s0));
+    transform_commit(0);
+    __syncthreads();
+    int cur = 0;
+
+    for (int k = 0;; ++k) {
+        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0;
+        const int n_item = item + (int)gridDim.x;
+        const int cout = cy * W4_COUTS + wave * 16 + ln;
+        const float bias = SPLITK ? 0.f : p.bias[cout];
+
+        auto step_body = [&](int step, auto first_tag) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool lasts = step + 1 == s1;
+            const int nvoff = lasts ? n_wvoff : wvoff;
+            const int nstep = lasts ? (SPLITK ? n_s0 : 0) : step + 1;
+            ab0 = cur * (W4_VBUF_FLOATS * 4) + va_lane;
+            ab1 = ab0 + W4_HALF * W4_PLANE_FLOATS * 4;
+            HP3D_OPAQUE_V(ab0);
+            HP3D_OPAQUE_V(ab1);
+            a_fetch(0, 0);
+            const int nsub_ = NSUB == 1 ? 0 : SPLITK ? HP3D_READFIRSTLANE(nstep / csteps) : lasts ? 0 : (step + 1) / csteps;
+            const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;
+            if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
+            else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
+#pragma unroll
+            for (int pl = 0; pl < W4_NP; ++pl) {
+                HP3D_SCHED_BARRIER();
+                if (pl < W4_NP - 1) a_fetch((pl & 1) ^ 1, pl + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {       // the two tile halves alternate: 40-cycle dependent latency vs 32-cycle issue
+                        if (FIRST && e == 0) {
+                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                            M[pl][m] = HP3D_MFMA_16x16x4(af[pl & 1][m][e], bq[pl % W4_RING][e], zero);
+                        } else {
+                            M[pl][m] = HP3D_MFMA_16x16x4(af[pl & 1][m][e], bq[pl % W4_RING][e], M[pl][m]);
+                        }
+                    }
+                if (pl == 0) window_fetch(NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (W4_CK * 4)) : ncs * (W4_CK * 4));
+                // weight prefetch W4_RING planes ahead into the slot this plane just released
+                const int t = pl + W4_RING;
+                if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
+                if (pl == W4_TRANSFORM_AT) transform_commit(cur ^ 1);
+            }
+            HP3D_SCHED_BARRIER();
+            __syncthreads();             // V[cur^1] complete, V[cur] free
+            cur ^= 1;
+        };
+        step_body(s0, std::true_type{});
+        {
+            const bool has_next = n_item < nitems;
+            if (has_next) split_of(n_item, n_kz, n_cy, n_tblock);
+            if (SPLITK) { n_kz = HP3D_READFIRSTLANE(n_kz); n_cy = HP3D_READFIRSTLANE(n_cy); n_tblock = HP3D_READFIRSTLANE(n_tblock); }
+            n_s0 = first_step_of(n_kz);
+            table_write(n_tblock, (k + 1) & 1, n_kz);
+            n_wvoff = (n_cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
+        }
+        for (int step = s0 + 1; step < s1; ++step) step_body(step, std::false_type{});
+
+        // ---- epilogue: Y = A^T M A per (tile, cout), bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store; a channel split stores its
+        //      raw sums into the [ksplit][B*Ho*Wo][Cout] scratch and conv_splitk_reduce adds them up in split order.
+        const int* tab = tinfo + (k & 1) * 2 * W4_TILES;
+        const bool cok = cout < p.cout_store;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int t = 16 * m + 4 * lq + r;          // MFMA row = Winograd tile
+                const int off = tab[t];
+                const int fl = tab[W4_TILES + t];
+                const int vo = (cok && off >= 0) ? (off + cout) * 4 : OOR;
+                float z[6][4];                               // A^T M: along the plane rows a
+#pragma unroll
+                for (int b = 0; b < 6; ++b)
+                    w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
+                          z[b][0], z[b][1], z[b][2], z[b][3]);
+                float y[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float x = y[i][j] + bias;
+                        if (!SPLITK && p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                        y[i][j] = x;
+                    }
+                }
+                if (POOL) {
+#pragma unroll
+                    for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                        for (int pj = 0; pj < 2; ++pj) {
+                            const float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1]));
+                            const bool ok = (pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2));
+                            HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
+                        }
+                } else {
+                    const int vr = fl & 15, vc = fl >> 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int vrow = i < vr ? vo : OOR;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, (i * Ws + j) * p.out_cs * 4);
+                    }
+                }
+            }
+        }
+        if (n_item >= nitems) break;
+        item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
+        if (SPLITK) { kz = n_kz; s0 = n_s0; s1 = first_step_of(n_kz + 1); }
+    }
+}
+
+}  // namespace
+
+// U = G g G^T per (virtual cin, cout), G of F(4x4,3x3), evaluated in double and rounded once; packed in conv_wino2's fragment
+// order with 36 planes: [plane a*6+b][step = vc / 16][Cout/16][q][n][e], virtual channel vc = 16 step + 4 q + e, cout 16 co16 + n
+// (zero padded).  Virtual channels as in wino_pack_weights (k = 7: nine 3x3 blocks of the filter zero-extended to 9x9).
+size_t wino4_packed_floats(int k, int cin_pad, int cout_pad) { return (size_t)W4_NP * (k == 7 ? 9 : 1) * cin_pad * cout_pad; }
+
+void wino4_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst) {
+    const double G[6][3] = {{1.0 / 4, 0, 0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const int nsub = k == 7 ? 9 : 1;
+    const int nst = nsub * cin_pad / 16, CO16 = cout_pad / 16;
+    memset(dst, 0, sizeof(float) * wino4_packed_floats(k, cin_pad, cout_pad));
+    for (int sub = 0; sub < nsub; ++sub) {
+        const int u0 = k == 7 ? 3 * (sub / 3) : 0, v0 = k == 7 ? 3 * (sub % 3) : 0;
+        for (int e_ = 0; e_ < cin_pad; ++e_) {
+            const int rc = chan_map ? chan_map[e_] : (e_ < Cin ? e_ : -1);
+            if (rc < 0) continue;
+            const int vc = sub * cin_pad + e_;
+            const int st = vc >> 4, q = (vc >> 2) & 3, e = vc & 3;
+            for (int co = 0; co < Cout; ++co) {
+                double w3[3][3];
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        w3[r][c] = (u0 + r < k && v0 + c < k) ? (double)g_hwio[((size_t)((u0 + r) * k + (v0 + c)) * Cin + rc) * Cout + co] : 0.0;
+                for (int a = 0; a < 6; ++a) {
+                    double ga[3];
+                    for (int c = 0; c < 3; ++c) ga[c] = G[a][0] * w3[0][c] + G[a][1] * w3[1][c] + G[a][2] * w3[2][c];
+                    for (int b = 0; b < 6; ++b) {
+                        const double s = ga[0] * G[b][0] + ga[1] * G[b][1] + ga[2] * G[b][2];
+                        dst[((((size_t)(a * 6 + b) * nst + st) * CO16 + (co >> 4)) * 4 + q) * 64 + (co & 15) * 4 + e] = (float)s;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Returns 1 when the layer can run here; *ksplit (may be NULL) receives the channel split that fills the chip (one workgroup per CU).
+int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit) {
+    if (ksplit) *ksplit = 1;
+    if ((k != 3 && k != 7) || stride != 1 || Cin % W4_CK || Cout % W4_COUTS) return 0;
+    // 32-bit offsets, and the column-outside-the-image constant needs the input below 2^30 bytes
+    if ((long)B * Ho * Wo * in_cs * 4 >= (1L << 30) || (long)B * Ho * Wo * out_cs * 4 >= (1L << 31)) return 0;
+    if (pool && (k != 3 || ((Ho | Wo) & 1))) return 0;
+    const long tiles = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4);
+    const long items = (tiles + W4_TILES - 1) / W4_TILES * (Cout / W4_COUTS);
+    const int slots = hp3d_num_cus();
+    if (items >= slots || !ksplit) return 1;
+    const int nsteps = (k == 7 ? 9 : 1) * Cin / W4_CK;
+    int ks = (int)(slots / items);
+    if (ks > nsteps / 2) ks = nsteps / 2;
+    if (ks > 32) ks = 32;
+    if (ks >= 2 && !pool && (long)ks * B * Ho * Wo * Cout * 4 < (1L << 31)) *ksplit = ks;
+    return 1;
+}
+
+template <bool POOL, int NSUB, bool SPLITK>
+static void wino4_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
+    static bool attr_done[64] = {};
+    auto k = conv_wino4_kernel<POOL, NSUB, SPLITK>;
+    if (hp3d_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM_BYTES);
+    const long items = (tiles + W4_TILES - 1) / W4_TILES * (p.Cout / W4_COUTS) * (SPLITK ? p.ksplit : 1);
+    const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU
+    dim3 grid((unsigned)(items < slots ? items : slots));
+    HP3D_LAUNCH(k, grid, dim3(256), W4_SMEM_BYTES, s, p);
+}
+
+// pin.ksplit > 1: pin.out must be the partial-sum scratch [ksplit][B*Ho*Wo][Cout] with out_cs = cout_store = Cout; the caller runs
+// conv_splitk_reduce afterwards (bias + activation happen there).
+int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
+    const long kso = pin.ksplit > 1 ? pin.ksplit : 1;
+    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || kso * pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
+    if (pin.nsub != 1 && pin.nsub != 9) return -1;
+    if (pin.Cout % W4_COUTS || pin.Cin % W4_CK) return -1;
+    ConvParams p = pin;
+    p.tiles_x = (p.Wo + 3) / 4;
+    p.tiles_y = (p.Ho + 3) / 4;
+    const long tiles = (long)p.B * p.tiles_x * p.tiles_y;
+    if (pool && (p.nsub != 1 || ((p.Ho | p.Wo) & 1))) return -1;
+    if (p.ksplit > 1) {
+        const int nsteps = p.nsub * p.Cin / W4_CK;
+        if (pool || p.ksplit * 2 > nsteps || p.out_cs != p.Cout) return -1;
+        if (p.nsub == 9) wino4_launch_t<false, 9, true>(p, tiles, s); else wino4_launch_t<false, 1, true>(p, tiles, s);
+        return 0;
+    }
+    p.ksplit = 1;
+    if (p.nsub == 9) wino4_launch_t<false, 9, false>(p, tiles, s);
+    else if (pool) wino4_launch_t<true, 1, false>(p, tiles, s);
+    else wino4_launch_t<false, 1, false>(p, tiles, s);
+    return 0;
+}

@@ -51,6 +51,7 @@ struct ConvL {
     size_t w_off, b_off;   // offsets into the blob (floats)
     size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
     size_t ww2_off = 0;    // the same filters in conv_wino2.hip's fragment order (two workgroups per CU), 0 = none
+    size_t ww4_off = 0;    // F(4x4,3x3) filters U[36][...] in conv_wino4.hip's fragment order (trunk nets), 0 = none
     size_t raw_off = 0;    // lifting nets only: [Cout/64][cin4][tap][64] for lift_fused.hip (one contiguous weight stream per wave), 0 = none
     int cin4 = 0;
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
@@ -90,6 +91,10 @@ struct Tables {
             blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
             l.ww2_off = blob_floats;
             blob_floats += wino_packed_floats(k, l.cin_pad, l.cout_pad);
+            if (net == NET_SEG || net == NET_POSE) {
+                l.ww4_off = blob_floats;
+                blob_floats += wino4_packed_floats(k, l.cin_pad, l.cout_pad);
+            }
         }
         if (net == NET_PRIOR || net == NET_VP) {
             l.cin4 = (cin + 15) / 16 * 16;          // four waves x whole channel quads
@@ -272,6 +277,8 @@ struct hp3d_ctx {
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
     int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12")
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
+    int use_wino4 = -1;        // conv_wino4.hip (Winograd F(4x4,3x3)): -1 auto (wino4_auto), 0 never, 1 wherever eligible, 2 PoseNet2D wherever eligible (option "wino4")
+    long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
     int micro_batch = -1;      // whole-path calls run in chunks of at most this many images (0: never split; -1 auto:
@@ -481,6 +488,15 @@ bool wino2_auto(int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int old
     return t_new < 0.97 * t_old;
 }
 
+// Which layers take the F(4x4,3x3) kernel by default (option "wino4" = "auto").  Numerics first: only PoseNet2D, where the end-to-end
+// effect was measured (heat-maps 4.7e-6 of 1e-3, profiles/r03_tuning_notes.md section 5); HandSegNet's score map feeds a threshold (the
+// hand mask), so it stays on F(2x2,3x3) unless the option forces it.  Then speed: measured per layer against conv_wino.hip
+// (profiles/r03_tuning_notes.md section 7).
+bool wino4_auto(bool posenet, int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int ks4) {
+    (void)k; (void)cin_pad; (void)cout_pad; (void)Ho; (void)Wo; (void)B; (void)ks4; (void)posenet;
+    return false;
+}
+
 // ---- one convolution layer -------------------------------------------------------------------
 // in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
 // f16 = 1 (trunk nets after hp3d_finalize_weights(dtype=1)): `in` / `out` hold halves (except the raw image of
@@ -497,11 +513,18 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     int wino_ks = 1, wino2_ks = 1;
     const int old_nt = (ctx->use_wino && !f16 && l.ww_off) ? conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool,
                                                                                  ctx->wino_splitk ? &wino_ks : nullptr) : 0;
-    if (ctx->use_wino && ctx->use_wino2 && !f16 && l.ww2_off && !ctx->conv_naive &&
+    int wino4_ks = 1;
+    const bool take4 = ctx->use_wino && ctx->use_wino4 && !f16 && l.ww4_off && !ctx->conv_naive &&
+        conv_wino4_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino4_ks : nullptr) &&
+        (ctx->use_wino4 == 1 || (ctx->use_wino4 == 2 && l.net == NET_POSE) ||
+         (ctx->use_wino4 < 0 && wino4_auto(l.net == NET_POSE, l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, wino4_ks)));
+    const bool take2 = !take4 && ctx->use_wino && ctx->use_wino2 && !f16 && l.ww2_off && !ctx->conv_naive &&
         conv_wino2_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino2_ks : nullptr) &&
-        (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live))) {
+        (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live));
+    if (take4 || take2) {
+        if (take4) wino2_ks = wino4_ks;          // (the block below serves both kernels: same parameters, same split / reduce protocol)
         ConvParams p;
-        p.in = in; p.wpk = ctx->blob + l.ww2_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.in = in; p.wpk = ctx->blob + (take4 ? l.ww4_off : l.ww2_off); p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
         p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
         p.cout_store = std::min(l.cout_pad, out_cs);
@@ -518,11 +541,15 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
             p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
         }
         {
-            ProfScope ps(ctx, l.name, l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
-                                      : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3", flops, bytes);
-            if (conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (2 workgroups per CU): launch refused");
+            const char* kn = take4 ? (l.k == 7 ? (wino2_ks > 1 ? "conv_wino4_f4x4_3x3_as7x7_splitk" : "conv_wino4_f4x4_3x3_as7x7")
+                                               : wino2_ks > 1 ? "conv_wino4_f4x4_3x3_splitk" : pool ? "conv_wino4_f4x4_3x3_pool" : "conv_wino4_f4x4_3x3")
+                                    : (l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
+                                               : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3");
+            ProfScope ps(ctx, l.name, kn, flops, bytes);
+            if (take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream))
+                HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", take4 ? "F(4x4,3x3)" : "2 workgroups per CU");
         }
-        ++ctx->conv_wino2_launches;
+        ++(take4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
         if (wino2_ks > 1) {
             ProfScope ps(ctx, l.name, pool ? "conv_splitk_reduce_pool" : "conv_splitk_reduce", 0.0, 4.0 * (wino2_ks + 1) * B * Ho * Wo * l.cout_pad);
             if (pool)
@@ -1048,7 +1075,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1387,6 +1414,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
+    if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto")) { ctx->use_wino4 = v == "auto" ? -1 : v == "1" ? 1 : v == "pose" ? 2 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
@@ -1489,6 +1517,7 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
             }
             wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww_off);
             wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww2_off);
+            if (l.ww4_off) wino4_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww4_off);
         }
     }
     for (const FcL& l : ctx->T.fc) {
@@ -1809,12 +1838,15 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
     int op_ks = 1, op_ks2 = 1;
-    if (ctx->use_wino && ctx->use_wino2 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
-        conv_wino2_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr)) {
-        // option "wino2" = "1": the two-workgroups-per-CU Winograd kernel (conv_wino2.hip)
-        const size_t wn = wino_packed_floats(k, l.cin_pad, l.cout_pad);
+    const bool op4 = ctx->use_wino && ctx->use_wino4 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
+        conv_wino4_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr);
+    if (op4 || (ctx->use_wino && ctx->use_wino2 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
+        conv_wino2_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr))) {
+        // option "wino4" = "1": the F(4x4,3x3) kernel (conv_wino4.hip); option "wino2" = "1": the two-workgroups-per-CU F(2x2,3x3) kernel
+        const size_t wn = op4 ? wino4_packed_floats(k, l.cin_pad, l.cout_pad) : wino_packed_floats(k, l.cin_pad, l.cout_pad);
         std::vector<float> pw(wn + l.cout_pad, 0.f);
-        wino2_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
+        if (op4) wino4_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
+        else wino2_pack_weights(w_hwio, k, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
         for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
         float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
         ConvParams p;
@@ -1829,8 +1861,9 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
             d_part = S.alloc<float>((size_t)op_ks2 * B * Ho * Wo * Cout); NN(ctx, d_part);
             p.out = d_part;
         }
-        if (conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (2 workgroups per CU): launch refused");
-        ++ctx->conv_wino2_launches;
+        if (op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream))
+            HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
+        ++(op4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
         if (op_ks2 > 1 && pool)
             conv_splitk_reduce_pool_launch(d_part, op_ks2, B, Ho, Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
         else if (op_ks2 > 1)
@@ -2033,6 +2066,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
+    if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }
     HP3D_FAIL(ctx, HP3D_ERR_ARG, "unknown counter %s", name);

@@ -226,6 +226,11 @@ size_t wino_packed_floats(int k, int cin_pad, int cout_pad);
 void wino2_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_wino2_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit);
 int conv_wino2_launch(const ConvParams& p, int pool, hipStream_t s);
+// conv_wino4.hip: Winograd F(4x4,3x3) (36 planes, one workgroup per CU); packed filters [36][step][Cout/16][q][n][e]
+size_t wino4_packed_floats(int k, int cin_pad, int cout_pad);
+void wino4_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
+int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit);
+int conv_wino4_launch(const ConvParams& p, int pool, hipStream_t s);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
 // debug cross-check (one thread per output element, obviously-correct loops)

@@ -97,7 +97,7 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_p
     (no waterfall loop), and (b) no scratch access lies inside the MFMA phase of a step / chunk loop (a spilled accumulator or
     address there drains the weight ring and has produced the slow builds recorded in the tuning notes)."""
     kernels = _kernel_disassembly(tmp_path)
-    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino2?_kernel|conv_h16_kernel', k)}
+    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[24]?_kernel|conv_h16_kernel', k)}
     assert len(hot) >= 8, sorted(kernels)[:20]
     for name, ins in hot.items():
         ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]

@@ -348,6 +348,36 @@ def test_winograd_two_workgroups_per_cu_kernel_on_interpreter(emu_engine, case):
         emu_engine.set_option('wino_splitk', '1')
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 8, 12, 96, 128, 1, 3),
+                                  (1, 17, 21, 32, 64, 0, 3), (1, 12, 14, 32, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7), (3, 10, 6, 16, 64, 1, 3)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d_k%d" % c)
+def test_winograd_f4x4_kernel_on_interpreter(emu_engine, case):
+    """conv_wino4.hip (option wino4 = 1) on the interpreter: F(4x4,3x3) with 36 planes -- 6x6 windows from row + column offset terms
+    (image borders, the 7x7 block shifts), in-place B^T d B, weight packing [36][step][Cout/16][q][n][e] from G evaluated in double,
+    A^T M A with ragged 4x4 tiles (sizes that are not multiples of 4), the fused pool as four maxima per tile, items that run on
+    into the next image, and the channel split."""
+    B, H, W, Cin, Cout, pool, k = case
+    rng = np.random.default_rng(sum(case) + 4)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('wino4', '1')
+    try:
+        for sk in ('0', '1'):
+            emu_engine.set_option('wino_splitk', sk)
+            n0 = emu_engine.counter('conv_wino4_launches')
+            y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+            assert emu_engine.counter('conv_wino4_launches') == n0 + 1
+            # F(4x4,3x3) in float32: ~10x the rounding error of F(2x2,3x3) per layer on unit-variance data
+            assert np.abs(y - r).max() < 1e-4, (sk, np.abs(y - r).max())
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+
+
 def test_lift_fused_one_launch_lifting_stage_on_interpreter(emu_engine, synth_weights):
     """lift_fused.hip (phases as launches on the interpreter): PosePrior + ViewpointNet conv / fc chains, stride-2 SAME padding,
     hand-side concat, K-slice partial sums finished by the consumer, bottleneck variant -- against the oracle and the layer-by-layer

@@ -172,6 +172,48 @@ def test_conv_winograd_two_workgroups_per_cu_7x7(gpu_engine, case):
     assert err < 5e-5
 
 
+W4_CASES = [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 17, 21, 32, 64, 0, 3), (1, 30, 40, 512, 512, 0, 3),
+            (1, 32, 32, 256, 256, 0, 3), (2, 60, 80, 128, 256, 1, 3), (3, 10, 6, 16, 64, 1, 3), (16, 64, 64, 256, 256, 0, 3), (16, 128, 128, 128, 128, 1, 3),
+            (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7)]
+
+
+@pytest.mark.parametrize("case", W4_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d_k%d" % c)
+def test_conv_winograd_f4x4_vs_oracle(gpu_engine, case):
+    """conv_wino4.hip (option wino4 = 1: Winograd F(4x4,3x3), 36 planes, 288 accumulators per lane) against the float64-accumulating
+    oracle on ragged sizes (not multiples of 4), the fused pool, items that continue into the next image, split channel steps, the
+    7x7 layers as nine blocks and the real PoseNet2D shapes; deterministic; the launch counter proves which kernel ran.  Tolerance:
+    F(4x4,3x3) multiplies by up to 8 / divides by up to 24 in float32 -- per layer on unit-variance data it is ~10x F(2x2,3x3)'s
+    error (gate here 2e-4; the conv_wino.hip test's is 5e-5); end to end the executor's gates stay 1e-3 / 1e-4."""
+    B, H, W, Cin, Cout, pool, k = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    big = B * H * W * Cout * k * k > 2.5e8          # the NumPy oracle needs minutes there: compare with conv_wino.hip instead (itself oracle-checked)
+    gpu_engine.set_option('wino4', '1')
+    try:
+        n0 = gpu_engine.counter('conv_wino4_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino4_launches') == n0 + 1
+        for _ in range(1 if big else 4):
+            assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, bool(pool))), "not deterministic"
+    finally:
+        gpu_engine.set_option('wino4', 'auto')
+    if big:
+        gpu_engine.set_option('wino4', '0')
+        gpu_engine.set_option('conv_impl', 'winograd')
+        try:
+            r = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        finally:
+            gpu_engine.set_option('conv_impl', 'mfma')
+            gpu_engine.set_option('wino4', 'auto')
+    else:
+        r = _conv_ref(x, w, b, 1, True, pool)
+    err = np.abs(y - r).max()
+    print("conv_wino4 %s max|err| %.3e" % (case, err))
+    assert y.shape == r.shape and err < 2e-4
+
+
 def test_conv_mfma_vs_naive_kernel(gpu_engine):
     """Same op through the obviously-correct one-thread-per-output kernel (debug path)."""
     rng = np.random.default_rng(7)

@@ -15,7 +15,11 @@ SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip',
 HEADERS = ['hp3d_common.h', 'lift_fused.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
-EXTRA_FLAGS = {}      # per-file additions, e.g. {'x.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+# per-file additions.  conv_wino4.hip: its F(4x4,3x3) transforms are multiply-adds by 2, 4, 5, 8 -- contracted to (packed) FMAs they are
+# a third fewer VALU instructions per step, and nothing in that file feeds a discontinuous decision (the later -ffp-contract wins)
+# (-pragma-unroll-threshold: its 36-plane step body is one straight-line block by design; past the default limit hipcc silently
+# stops unrolling and the 288 accumulators land in scratch)
+EXTRA_FLAGS = {'conv_wino4.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000']}
 
 
 def _stale(target, deps):

@@ -26,6 +26,22 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef HP3D_W4_ABL
+#define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
+#endif
+
+#ifndef HP3D_W4_ORDER
+#define HP3D_W4_ORDER 1            // 1: XCD-affine item order (conv3_2 -6 %), 0: cout-block-major like conv_wino.hip
+#endif
+#ifndef HP3D_W4_NT
+#define HP3D_W4_NT 0
+#endif
+#if HP3D_W4_NT
+#define W4_WLOAD HP3D_BUFFER_LOAD8_NT
+#else
+#define W4_WLOAD HP3D_BUFFER_LOAD8
+#endif
+
 namespace {
 
 constexpr int W4_TILES = 32;                       // Winograd tiles (4x4 outputs each) per item
@@ -40,7 +56,20 @@ constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4;    
 #endif
 constexpr int W4_RING = HP3D_W4_RING;              // weight fragments in flight (planes); must divide 36
 static_assert(W4_NP % W4_RING == 0, "static ring slots need a ring that divides the plane count");
+#ifndef HP3D_W4_ADEPTH
+#define HP3D_W4_ADEPTH 2
+#endif
+constexpr int W4_ADEPTH = HP3D_W4_ADEPTH;          // A fragments (planes) in flight from LDS: a plane is only 8 MFMAs = 256 cycles, and with one wave
+static_assert(W4_NP % W4_ADEPTH == 0, "");         // per SIMD an LDS round trip that is not covered idles the matrix core
 constexpr int W4_HALF = 18;                        // planes reachable from one LDS base (16-bit immediate offsets)
+constexpr int W4_AGPR_PLANES = 32;                 // planes whose accumulators live in AGPRs (32 x 8 = 256); the rest in arch VGPRs
+#ifndef HP3D_W4_WPP
+#define HP3D_W4_WPP 2
+#endif
+constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: the 36 loads of the next step's window are SPREAD over the first
+                                                   // 36 / W4_WPP planes.  Loads return in issue order, so a weight fragment issued behind a burst of
+                                                   // 36 x 4 waves window loads waits for the whole burst to pass the CU's one address unit
+                                                   // (measured: the wave stalled at plane 9 of every step, 25 % of the kernel's time)
 constexpr int W4_TRANSFORM_AT = 29;                // the plane under which the next step's windows are transformed
 
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
@@ -131,6 +160,12 @@ void conv_wino4_kernel(const ConvParams p) {
         for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * p.W * cs4 : OOR;
 #pragma unroll
         for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * cs4 : COL_OOR;
+#if HP3D_W4_ABL & 128        // hot windows: every load of the launch comes from one 18 KB region
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ro[r] = r * 3072 + lp * 8 + (lt & 7) * 64;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) co[c] = c * 512;
+#endif
     };
     auto loader_setup = [&](int tblock, bool valid, int sub) {
         int lb, lty, ltx;
@@ -145,25 +180,28 @@ void conv_wino4_kernel(const ConvParams p) {
     f32x2 d[36];
     auto window_fetch = [&](int soff) {
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
-#pragma unroll
-            for (int c = 0; c < 6; ++c) d[r * 6 + c] = HP3D_BUFFER_LOAD8(irsrc, (int)((unsigned)ro[r] + (unsigned)co[c]), soff);
+        for (int e = 0; e < 36; ++e) d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), soff);
     };
     float* const Vw = V + lt * W4_CK + ((lp >> 1) ^ w4_swz(lt)) * 4 + (lp & 1) * 2;      // this thread's slot in plane 0 of buffer 0
     auto transform_commit = [&](int buf) {
         // B^T d B in place: along the window rows first (plane row a), then along the columns (plane column b) straight into LDS
 #pragma unroll
-        for (int c = 0; c < 6; ++c) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
+        for (int c = 0; c < 6; ++c)
+            if (!(HP3D_W4_ABL & 32)) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
         float* Vq0 = Vw + buf * W4_VBUF_FLOATS;
         float* Vq1 = Vq0 + W4_HALF * W4_PLANE_FLOATS;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-            w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
+            if (!(HP3D_W4_ABL & 32)) w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
 #pragma unroll
             for (int b = 0; b < 6; ++b) {
                 const int pl = a * 6 + b;
                 float* dst = pl < W4_HALF ? Vq0 + pl * W4_PLANE_FLOATS : Vq1 + (pl - W4_HALF) * W4_PLANE_FLOATS;
+#if HP3D_W4_ABL & 64
+                asm volatile("" :: "v"(d[pl]));
+#else
                 *(f32x2*)dst = d[pl];
+#endif
             }
         }
     };
@@ -185,7 +223,7 @@ void conv_wino4_kernel(const ConvParams p) {
     auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
     const int va_lane = (ln * W4_CK + ((lq ^ w4_swz(ln)) * 4)) * 4;
     int ab0 = 0, ab1 = 0;
-    f32x4 af[2][2];
+    f32x4 af[W4_ADEPTH][2];
     auto a_fetch = [&](int set, int plane) {
         const int base = plane < W4_HALF ? ab0 : ab1, pl = plane < W4_HALF ? plane : plane - W4_HALF;
 #pragma unroll
@@ -195,6 +233,16 @@ void conv_wino4_kernel(const ConvParams p) {
     auto split_of = [&](int it, int& kz, int& cy_, int& tb_) {
         kz = SPLITK ? it / per_split : 0;
         const int r = SPLITK ? it - kz * per_split : it;
+#if HP3D_W4_ORDER
+        // XCD-affine order: workgroup ids go round-robin over the 8 XCDs; within an XCD consecutive items are the cout blocks of ONE
+        // tile block, so its windows are fetched from the fabric once per XCD and re-read from that XCD's L2
+        if ((tile_blocks & 7) == 0) {
+            const int xcd = r & 7, j = r >> 3, tbq = j / ncy;
+            cy_ = j - tbq * ncy;
+            tb_ = tbq * 8 + xcd;
+            return;
+        }
+#endif
         cy_ = r / tile_blocks;
         tb_ = r - cy_ * tile_blocks;
     };
@@ -204,6 +252,7 @@ void conv_wino4_kernel(const ConvParams p) {
     split_of(item, kz, cy, tblock);
     int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
     const int sub0 = (NSUB > 1 && SPLITK) ? HP3D_READFIRSTLANE(s0 / csteps) : 0;
+    int sub_cur = sub0;                           // block (i, j) = (sub_cur / 3, sub_cur % 3) of the 9x9 extension the current step belongs to
     loader_setup(tblock, true, sub0);
     table_write(tblock, 0, kz);
     int wvoff = (cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
@@ -223,42 +272,55 @@ void conv_wino4_kernel(const ConvParams p) {
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool lasts = step + 1 == s1;
+            const bool za = sub_cur >= 6, zb = sub_cur == 2 || sub_cur == 5 || sub_cur == 8;
+            const int skip_a = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR(za ? 1 : 0) : 0;
+            const int skip_b = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR(zb ? 1 : 0) : 0;
+            const int skip_ab = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR((za || zb) ? 1 : 0) : 0;
             const int nvoff = lasts ? n_wvoff : wvoff;
             const int nstep = lasts ? (SPLITK ? n_s0 : 0) : step + 1;
             ab0 = cur * (W4_VBUF_FLOATS * 4) + va_lane;
             ab1 = ab0 + W4_HALF * W4_PLANE_FLOATS * 4;
             HP3D_OPAQUE_V(ab0);
             HP3D_OPAQUE_V(ab1);
-            a_fetch(0, 0);
+#pragma unroll
+            for (int t = 0; t < W4_ADEPTH - 1; ++t) a_fetch(t, t);
             const int nsub_ = NSUB == 1 ? 0 : SPLITK ? HP3D_READFIRSTLANE(nstep / csteps) : lasts ? 0 : (step + 1) / csteps;
             const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;
             if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
+            const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (W4_CK * 4)) : ncs * (W4_CK * 4);
 #pragma unroll
             for (int pl = 0; pl < W4_NP; ++pl) {
                 HP3D_SCHED_BARRIER();
-                if (pl < W4_NP - 1) a_fetch((pl & 1) ^ 1, pl + 1);
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-#pragma unroll
-                    for (int m = 0; m < 2; ++m) {       // the two tile halves alternate: 40-cycle dependent latency vs 32-cycle issue
-                        if (FIRST && e == 0) {
-                            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                            M[pl][m] = HP3D_MFMA_16x16x4(af[pl & 1][m][e], bq[pl % W4_RING][e], zero);
-                        } else {
-                            M[pl][m] = HP3D_MFMA_16x16x4(af[pl & 1][m][e], bq[pl % W4_RING][e], M[pl][m]);
-                        }
-                    }
-                if (pl == 0) window_fetch(NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (W4_CK * 4)) : ncs * (W4_CK * 4));
+                if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
+                // the eight MFMAs of the plane (two tile halves alternating: 40-cycle dependent latency vs 32-cycle issue) as ONE
+                // statement that pins the accumulators' register file: planes 0..31 in the 256 AGPRs, planes 32..35 in arch VGPRs.
+                // 7x7 filters: in the edge blocks of the zero-extended 9x9 filter (i = 2 / j = 2: one filter row / column of three)
+                // G g G^T has a zero row a = 5 / column b = 5: those planes' MFMAs are skipped (289 instead of 324 plane-steps).
+                const int skip = (NSUB == 9 && !FIRST) ? ((pl / 6 == 5 && pl % 6 == 5) ? skip_ab : pl / 6 == 5 ? skip_a : pl % 6 == 5 ? skip_b : 0) : 0;
+                if (FIRST) {
+                    if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_FIRST("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
+                    else HP3D_MFMA16_PLANE_FIRST("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
+                } else {
+                    if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_UNLESS("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
+                    else HP3D_MFMA16_PLANE_UNLESS("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
+                }
                 // weight prefetch W4_RING planes ahead into the slot this plane just released
                 const int t = pl + W4_RING;
-                if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                if (HP3D_W4_ABL & 8) {}
+                else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
                 else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
-                if (pl == W4_TRANSFORM_AT) transform_commit(cur ^ 1);
+                if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
+#pragma unroll
+                    for (int j = 0; j < W4_WPP; ++j)          // (indices are constants once the plane loop is unrolled)
+                        d[pl * W4_WPP + j] = W4_WLOAD(irsrc, (int)((unsigned)ro[(pl * W4_WPP + j) / 6] + (unsigned)co[(pl * W4_WPP + j) % 6]), wsoff);
+                }
+                if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) transform_commit(cur ^ 1);
             }
             HP3D_SCHED_BARRIER();
-            __syncthreads();             // V[cur^1] complete, V[cur] free
+            if (!(HP3D_W4_ABL & 4)) __syncthreads();             // V[cur^1] complete, V[cur] free
             cur ^= 1;
+            sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };
         step_body(s0, std::true_type{});
         {

@@ -277,7 +277,8 @@ struct hp3d_ctx {
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
     int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12")
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
-    int use_wino4 = -1;        // conv_wino4.hip (Winograd F(4x4,3x3)): -1 auto (wino4_auto), 0 never, 1 wherever eligible, 2 PoseNet2D wherever eligible (option "wino4")
+    int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
+                               // model), 0 never, 1 wherever eligible (tests)
     long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
@@ -488,13 +489,58 @@ bool wino2_auto(int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int old
     return t_new < 0.97 * t_old;
 }
 
-// Which layers take the F(4x4,3x3) kernel by default (option "wino4" = "auto").  Numerics first: only PoseNet2D, where the end-to-end
-// effect was measured (heat-maps 4.7e-6 of 1e-3, profiles/r03_tuning_notes.md section 5); HandSegNet's score map feeds a threshold (the
-// hand mask), so it stays on F(2x2,3x3) unless the option forces it.  Then speed: measured per layer against conv_wino.hip
-// (profiles/r03_tuning_notes.md section 7).
-bool wino4_auto(bool posenet, int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int ks4) {
-    (void)k; (void)cin_pad; (void)cout_pad; (void)Ho; (void)Wo; (void)B; (void)ks4; (void)posenet;
-    return false;
+// Which layers take the F(4x4,3x3) kernel (option "wino4" = "auto": both trunks; "pose": PoseNet2D only).  Numerics: end to end the larger
+// Winograd tile moves PoseNet2D's heat-maps by 5e-6 (gate 1e-3) and the 3-D keypoints by 3e-6 (gate 1e-4).  HandSegNet's score map
+// feeds a THRESHOLD (the hand mask), where any change of summation order flips pixels whose two logits are equal to rounding: against
+// the all-direct-kernel run, 24 of 512 synthetic images differ in at least one mask pixel with F(2x2,3x3) and 35 with F(4x4,3x3); the
+// crop box and the keypoints (1e-4) agree on all 512 either way (scripts/mask_flip_rate.py, profiles/r03_tuning_notes.md section 7).
+// Speed: the cost model below, fitted to per-layer timings of the three Winograd kernels at B = 1 ... 32.
+// what option "wino4" = "auto" means: both trunks by the cost model below (-2).  HP3D_WINO4_AUTO=pose in the environment keeps
+// HandSegNet on F(2x2,3x3) (-1; the same as option "wino4" = "pose") -- for A/B runs of whole test suites.
+static int wino4_default() {
+    const char* e = getenv("HP3D_WINO4_AUTO");
+    return (e && !strcmp(e, "pose")) ? -1 : -2;
+}
+bool wino4_auto(int mode, bool posenet, int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int ks4, int old_nt, int old_ks, int ks2,
+                bool two_streams) {
+    if (mode == -1 && !posenet) return false;              // auto: PoseNet2D only; "all": both trunks
+    if ((long)B * Ho * Wo < 1024) return false;
+    const double cus = hp3d_num_cus(), reduce_cost = 0.7;
+    const int nsub = k == 7 ? 9 : 1;
+    // units: one conv_wino.hip item-step (32 F(2x2) tiles x 128 couts x 32 channels).  A conv_wino4 item-step (32 F(4x4) tiles x 64
+    // couts x 16 channels) covers the same amount of convolution and was measured at 0.72-0.78 of its time on filled launches
+    // (7x7 layers 0.85: their split partial sums go through a reduce launch).  With the second stream live the other half's kernels
+    // fill tail rounds, so rounds count fractionally.
+    auto rounds = [&](double items) { return two_streams ? std::max(1.0, items / cus) : std::ceil(items / cus); };
+    double t_best = 1e30;
+    if (old_nt) {
+        const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+        const long items1 = (tiles + old_nt - 1) / old_nt * (cout_pad / (old_nt == 32 ? 128 : 64));
+        const int S1 = nsub * cin_pad / (old_nt == 32 ? 32 : 16);
+        const double w1 = old_nt == 32 ? 1.0 : 0.5;
+        t_best = old_ks > 1 ? std::ceil((double)S1 / old_ks) * w1 * std::max(1.0, items1 * old_ks / cus) + reduce_cost : rounds((double)items1) * S1 * w1;
+    }
+    {
+        const long tiles = (long)B * ((Ho + 1) / 2) * ((Wo + 1) / 2);
+        const long items2 = (tiles + 31) / 32 * (cout_pad / 64);
+        const int S2 = nsub * cin_pad / 16;
+        const double t2 = ks2 > 1 ? 1.07 * (std::ceil((double)S2 / ks2) * 0.25 * std::max(1.0, items2 * ks2 / cus)) + reduce_cost
+                                  : 1.07 * (items2 * S2 * 0.25 / cus + S2 * 0.125);
+        t_best = std::min(t_best, t2);
+    }
+    const long tiles4 = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4);
+    const long items4 = (tiles4 + 31) / 32 * (cout_pad / 64);
+    const int S4 = nsub * cin_pad / 16;
+    if (ks4 > 1 && (S4 + ks4 - 1) / ks4 < 8) return false;      // short split items are all prologue / epilogue (measured: B <= 2 loses)
+    const double c4 = k == 7 ? 0.85 : 0.76;
+    const double t4 = ks4 > 1 ? c4 * std::ceil((double)S4 / ks4) * std::max(1.0, items4 * ks4 / cus) + reduce_cost : c4 * rounds((double)items4) * S4;
+    return t4 < 0.97 * t_best;
+}
+
+static int wino2_ks_probe(hp3d_ctx* ctx, const ConvL& l, int Ho, int Wo, int B, int in_cs, int out_cs, int pool) {
+    int ks = 1;
+    (void)conv_wino2_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &ks : nullptr);
+    return ks;
 }
 
 // ---- one convolution layer -------------------------------------------------------------------
@@ -516,8 +562,9 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     int wino4_ks = 1;
     const bool take4 = ctx->use_wino && ctx->use_wino4 && !f16 && l.ww4_off && !ctx->conv_naive &&
         conv_wino4_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino4_ks : nullptr) &&
-        (ctx->use_wino4 == 1 || (ctx->use_wino4 == 2 && l.net == NET_POSE) ||
-         (ctx->use_wino4 < 0 && wino4_auto(l.net == NET_POSE, l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, wino4_ks)));
+        (ctx->use_wino4 == 1 ||
+         (ctx->use_wino4 < 0 && wino4_auto(ctx->use_wino4, l.net == NET_POSE, l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, wino4_ks, old_nt, wino_ks,
+                                           wino2_ks_probe(ctx, l, Ho, Wo, B, in_cs, out_cs, pool), ctx->two_streams_live)));
     const bool take2 = !take4 && ctx->use_wino && ctx->use_wino2 && !f16 && l.ww2_off && !ctx->conv_naive &&
         conv_wino2_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino2_ks : nullptr) &&
         (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live));
@@ -1269,6 +1316,7 @@ int hp3d_create(int device, hp3d_ctx** out) {
     }
     hp3d_ctx* ctx = new hp3d_ctx();
     ctx->device = device;
+    ctx->use_wino4 = wino4_default();
     if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&ctx->stream) != hipSuccess) {
         set_error(nullptr, "hp3d_create: hipSetDevice/hipStreamCreate failed");
         delete ctx;
@@ -1414,7 +1462,10 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
-    if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto")) { ctx->use_wino4 = v == "auto" ? -1 : v == "1" ? 1 : v == "pose" ? 2 : 0; return 0; }
+    if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
+        ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
+        return 0;
+    }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }

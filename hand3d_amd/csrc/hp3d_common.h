@@ -64,6 +64,38 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  : "v"((a0)[0]), "v"((a0)[1]), "v"((a0)[2]), "v"((a0)[3]), "v"((a1)[0]), "v"((a1)[1]), "v"((a1)[2]),   \
                    "v"((a1)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]), "s"(skip)                     \
                  : "scc")
+// conv_wino4.hip's plane-step with the accumulators' register class PINNED by the constraint (REG = "a": AGPRs, "v": arch VGPRs): the
+// kernel holds 72 accumulator tuples = 288 registers, more than the 256 AGPRs; left to itself hipcc shuttles ~10 tuples per step
+// between the two files (80 v_accvgpr moves in the MFMA stream).  Planes 0..31 are pinned to AGPRs, planes 32..35 to VGPRs.
+#define HP3D_MFMA16_PLANE_UNLESS(REG, acc0, acc1, a0, a1, b4, skip)                                                  \
+    asm volatile("s_cmp_lg_u32 %14, 0\n\t"                                                                         \
+                 "s_cbranch_scc1 .Lhp3d_skip%=\n\t"                                                                \
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %10, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %6, %10, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %11, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %8, %12, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %13, %1\n"                                                         \
+                 ".Lhp3d_skip%=:"                                                                                   \
+                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
+                 : "v"((a0)[0]), "v"((a0)[1]), "v"((a0)[2]), "v"((a0)[3]), "v"((a1)[0]), "v"((a1)[1]), "v"((a1)[2]),   \
+                   "v"((a1)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]), "s"(skip)                     \
+                 : "scc")
+// the first step of an item: the accumulators start from the inline constant 0 (never skipped)
+#define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                                                         \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, 0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %1, %6, %10, 0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %11, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %7, %11, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %12, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %8, %12, %1\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %0, %5, %13, %0\n\t"                                                      \
+                 "v_mfma_f32_16x16x4_f32 %1, %9, %13, %1"                                                            \
+                 : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
+                 : "v"((a0)[0]), "v"((a0)[1]), "v"((a0)[2]), "v"((a0)[3]), "v"((a1)[0]), "v"((a1)[1]), "v"((a1)[2]),   \
+                   "v"((a1)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]))
 // a wave-uniform int held in an SGPR that the compiler cannot trace back to a VGPR (it does propagate
 // __builtin_amdgcn_readfirstlane's argument into an inline-asm "s" operand and then fails to assemble)
 static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
@@ -126,6 +158,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 8 B per lane (same addressing / range check)
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) \
     __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 0))
+// 8 B per lane, non-temporal (nt): a streaming read that should not displace other lines of the L2
+#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 2))
 // 16 B per lane at agent scope (sc1): the consuming side of an in-launch hand-off whose payload was stored write-through
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 16))
@@ -153,6 +188,7 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
+#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))

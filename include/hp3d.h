@@ -77,6 +77,13 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            launches that under-fill or badly quantise conv_wino's grid (small batches), conv_wino for B = 32;
  *                            "1" = wherever the shape allows (tests); "0" = never.  Same arithmetic: results agree to
  *                            accumulation order;
+ *          "wino4"        = "auto" (default) | "pose" | "0" | "1": Winograd F(4x4,3x3) (conv_wino4.hip: 36 products per 4x4 outputs, 2.25
+ *                            multiply-adds per output instead of F(2x2,3x3)'s 4) for the 3x3 / 7x7 layers.  auto = every trunk layer a
+ *                            per-layer cost model of the three Winograd kernels gives to it (filled launches: B >= 4 ... 8); "pose" =
+ *                            PoseNet2D only (HandSegNet's score map feeds the mask threshold: with "auto" ~2 % more images differ from
+ *                            the all-direct-kernel run in a mask pixel -- never in the crop box or, beyond 1e-4, in a keypoint over 512
+ *                            images, scripts/mask_flip_rate.py); "1" = wherever the shape allows (tests); "0" = never.  Float32
+ *                            throughout; end to end it moves heat-maps by 5e-6 and 3-D keypoints by 3e-6;
  *          "lift_fused"   = "auto" (default) | "0" | "1": PosePrior + ViewpointNet + the lifting epilogue
  *                            (ColorHandPose3DNetwork.py:221-334) as ONE persistent launch with grid barriers (lift_fused.hip)
  *                            instead of 24 launches.  auto = for at most 4 images per call (the stage is latency-bound there:
@@ -230,7 +237,8 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
 /* Executor counters: "graph_captures" / "graph_replays" = hipGraphs instantiated / launched since hp3d_create (option
  * "graph" = "1"; a replay happens only with per-launch profiling off); "conv_h16_launches" = half-precision trunk
  * layers that ran on conv_h16.hip (option "f16_impl"); "conv_wino2_launches" = float32 layers that ran on conv_wino2.hip (option
- * "wino2"); "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
+ * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4");
+ * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);
 

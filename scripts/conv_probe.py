@@ -1,5 +1,5 @@
 """One convolution layer through the per-op entry point, under both Winograd kernels (for rocprofv3 --pmc passes).
-usage: python scripts/conv_probe.py B H W Cin Cout pool [k]"""
+usage: python scripts/conv_probe.py B H W Cin Cout pool [k [wino,wino2,wino4]]"""
 import sys
 import numpy as np
 import os
@@ -12,9 +12,11 @@ rng = np.random.default_rng(0)
 x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
 w = (rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)
 b = rng.standard_normal(Cout).astype(np.float32)
-for mode in ('0', '1'):
-    e.set_option('wino2', mode)
+modes = sys.argv[8].split(',') if len(sys.argv) > 8 else ['wino', 'wino2']
+for mode in modes:          # wino = conv_wino.hip, wino2 = conv_wino2.hip, wino4 = conv_wino4.hip (F(4x4,3x3))
+    e.set_option('wino2', '1' if mode == 'wino2' else '0')
+    e.set_option('wino4', '1' if mode == 'wino4' else '0')
     e.set_option('conv_impl', 'winograd')
     for _ in range(3):
         y = e.conv2d(x, w, b, 1, True, bool(pool))
-    print('wino2 =', mode, float(np.abs(y).mean()))
+    print(mode, float(np.abs(y).mean()))

@@ -7,21 +7,4 @@ for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   echo "$N exit $?"
 done
 cd $R
-python - <<PY
-import csv,glob,collections
-agg=collections.OrderedDict()
-for f in sorted(glob.glob('$OUT/*/p_counter_collection.csv')):
-    for r in csv.DictReader(open(f)):
-        n=r['Kernel_Name']
-        if 'conv_wino' not in n: continue
-        key=n[n.find('conv_wino'):n.find('(')] if '(' in n else n
-        d=agg.setdefault(key,collections.defaultdict(list))
-        d[r['Counter_Name']].append(float(r['Counter_Value']))
-        d['dur'].append(int(r['End_Timestamp'])-int(r['Start_Timestamp']))
-for k,d in agg.items():
-    m={c:sum(v)/len(v) for c,v in d.items()}
-    dur=m['dur']; clock=m.get('SQ_BUSY_CYCLES',0)/32/dur if dur else 0
-    print(k)
-    print('  dur us %.1f clock %.2f mfma_busy %.3f wait %.3f issue_wait %.3f active %.3f'%(dur/1e3,clock,m.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/(dur*clock) if clock else 0, m.get('SQ_WAIT_ANY',0)/max(m.get('SQ_WAVE_CYCLES',1),1), m.get('SQ_WAIT_INST_ANY',0)/max(m.get('SQ_WAVE_CYCLES',1),1), m.get('SQ_ACTIVE_INST_ANY',0)/max(m.get('SQ_WAVE_CYCLES',1),1)))
-    print('  ', {c:round(v) for c,v in m.items() if c!='dur'})
-PY
+python scripts/w2pmc_summary.py $OUT

@@ -87,6 +87,7 @@ static inline f32x2 hp3d_emu_buffer_load8(hp3d_rsrc_t r, unsigned voff, unsigned
     return v;
 }
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) hp3d_emu_buffer_load8((rsrc), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) hp3d_emu_buffer_load8((rsrc), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }
@@ -137,6 +138,13 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
                 (acc0) = hp3d_emu_mfma_16x16x4((a0)[_e], (b4)[_e], (acc0));       \
                 (acc1) = hp3d_emu_mfma_16x16x4((a1)[_e], (b4)[_e], (acc1));       \
             }                                                                     \
+    } while (0)
+#define HP3D_MFMA16_PLANE_UNLESS(REG, acc0, acc1, a0, a1, b4, skip) HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, skip)
+#define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                      \
+    do {                                                                          \
+        const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                    \
+        (acc0) = _z; (acc1) = _z;                                                 \
+        HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, 0);                        \
     } while (0)
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }

@@ -95,6 +95,19 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     assert np.abs(small_w - rs).max() < 1e-5
     for a, b in zip(sms_w, ref):
         assert np.abs(a - b).max() < 1e-5
+    # ... and onto conv_wino4.hip (F(4x4,3x3)): the executor's packed 36-plane filters, pooled layers, ragged 4x4 tiles at 16 x 24 and
+    # its pooled sizes, the 7x7 units with the concat-channel permutation
+    emu_engine.set_option('wino4', '1')
+    try:
+        n0 = emu_engine.counter('conv_wino4_launches')
+        _, small_4 = emu_engine.handsegnet(img, want_small=True)
+        sms_4 = net.inference_pose2d(crop)
+        assert emu_engine.counter('conv_wino4_launches') >= n0 + 30
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+    assert np.abs(small_4 - rs).max() < 3e-5
+    for a, b in zip(sms_4, ref):
+        assert np.abs(a - b).max() < 3e-5
     rng = np.random.default_rng(5)
     sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
     hs = synth.hand_sides(2)

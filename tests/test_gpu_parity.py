@@ -214,6 +214,46 @@ def test_conv_winograd_f4x4_vs_oracle(gpu_engine, case):
     assert y.shape == r.shape and err < 2e-4
 
 
+def test_full_pipeline_winograd_f4x4_policy(gpu_engine, synth_weights):
+    """Option wino4 on the whole path (B = 16, 240x320): "0" runs no conv_wino4 launch, "pose" only PoseNet2D's, "auto" (the default)
+    both trunks'; all three give the same crop box and 2-D keypoints, score maps / heat-maps / 3-D keypoints agree to float32 Winograd
+    rounding (1e-4 score-map logits... measured 1e-5, 2e-5 heat-maps, 1e-5 keypoints: two orders inside the north-star gates 1e-3 / 1e-4),
+    and a hand mask may differ from the F(2x2,3x3) run's only in pixels whose two logits are equal to rounding."""
+    gpu_engine.load_weight_dict(synth_weights)
+    gpu_engine.finalize_weights()
+    img = synth.make_batch(700, 16, 240, 320)
+    hs = synth.hand_sides(16)
+    outs, counts = {}, {}
+    try:
+        for mode in ('0', 'pose', 'auto'):
+            gpu_engine.set_option('wino4', mode)
+            n0 = gpu_engine.counter('conv_wino4_launches')
+            outs[mode] = gpu_engine.infer_full(img, hs, want_mask=True, outputs=('scoremap', 'scale', 'center', 'kpmap', 'coord3d', 'kp_crop'))
+            counts[mode] = gpu_engine.counter('conv_wino4_launches') - n0
+    finally:
+        gpu_engine.set_option('wino4', 'auto')
+    print("conv_wino4 launches per call:", counts)
+    assert counts['0'] == 0 and 0 < counts['pose'] < counts['auto']
+    r = outs['0']
+    for mode in ('pose', 'auto'):
+        o = outs[mode]
+        assert np.array_equal(o['center'], r['center']) and np.array_equal(o['scale'], r['scale']), mode
+        assert np.array_equal(o['kp_crop'], r['kp_crop']), mode
+        d_sm = np.abs(o['scoremap'] - r['scoremap']).max()
+        d_hm = np.abs(o['kpmap'] - r['kpmap']).max()
+        d_kp = np.abs(o['coord3d'] - r['coord3d']).max()
+        print("wino4=%s vs F(2x2,3x3): score map %.2e, heat-maps %.2e, 3-D keypoints %.2e" % (mode, d_sm, d_hm, d_kp))
+        assert d_sm < 1e-4 and d_hm < 1e-4 and d_kp < 2e-5, mode
+        if mode == 'pose':
+            assert np.array_equal(o['mask'], r['mask'])          # HandSegNet untouched: identical masks
+        else:
+            # the class decision per pixel may only change where the two logits are equal to rounding
+            det_o = o['scoremap'][..., 1] > o['scoremap'][..., 0]
+            det_r = r['scoremap'][..., 1] > r['scoremap'][..., 0]
+            margin = np.abs(r['scoremap'][..., 1] - r['scoremap'][..., 0])
+            assert (margin[det_o != det_r] < 1e-4).all(), "a pixel with a clear logit margin changed class"
+
+
 def test_conv_mfma_vs_naive_kernel(gpu_engine):
     """Same op through the obviously-correct one-thread-per-output kernel (debug path)."""
     rng = np.random.default_rng(7)

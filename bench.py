@@ -325,14 +325,16 @@ def main():
         # half-precision 3x3 trunk kernel incl. its pooled and fused-first-block forms), conv_first (conv1_1), glue
         fam = {}
         for name, kern, ms, fl, by in rows:
-            k = ('conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
+            k = ('conv_wino4' if kern.startswith('conv_wino4') else 'conv_wino2' if kern.startswith('conv_wino2') else
+                 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
                  'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
             # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
             # nine 3x3 blocks of its zero-extended 9x9 form, minus the structurally zero planes of the edge blocks (round 3):
             # (4*16 + 4*12 + 9) = 121 plane products per 4*49
-            # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks: 324/784
-            exe = ((324.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if kern.startswith('conv_wino4') else
-                   (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0)) if k == 'conv_wino' else 1.0
+            # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks minus
+            # their structurally zero planes: (4*36 + 4*30 + 25) = 289 plane products per 16*49
+            exe = ((289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
+                   (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k in ('conv_wino', 'conv_wino2') else 1.0)
             f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
             f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
         total_ms = max(sum(v[0] for v in fam.values()), 1e-9)
@@ -362,17 +364,20 @@ def main():
         if dom == 'conv_h16':
             roof["note"] = ("half-precision 3x3 trunk kernel (all instantiations: 1 / 2 / 4 cout blocks per wave, pooled, fused conv1_1 + conv1_2); "
                             "direct form, so executed = algorithmic; the fused launches count conv1_1's FLOPs too")
-        if dom == 'conv_wino':
-            roof["note"] = ("float32 Winograd: F(2x2,3x3) executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
-                            "blocks without their structurally zero planes: 121/196), F(4x4,3x3) (kernels named conv_wino4_*) 36/144 "
-                            "(7x7: 324/784); frac is the executed matrix-core rate over the dense f32 MFMA peak")
+        if dom in ('conv_wino', 'conv_wino2'):
+            roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
+                            "blocks without their structurally zero planes: 121/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
+        if dom == 'conv_wino4':
+            roof["note"] = ("float32 Winograd F(4x4,3x3) (conv_wino4.hip): executes 36/144 of the direct-form multiply-adds (7x7 layers as nine "
+                            "3x3 blocks without their structurally zero planes: 289/784); frac is the executed matrix-core rate over the dense "
+                            "f32 MFMA peak, achieved_algorithmic the direct-form FLOPs over the same time")
         workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step" % (H, W, B)) \
             if a.workload == 'full' else ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B)
         roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str, a.dtype)
         roof["timing"] = "HIP events on the engine stream around each launch, separate pass of %d steps (%.3f ms/step profiled)" % (
             a.steps, dt_prof / a.steps * 1e3)
         others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0])
-                  if k != dom and k in ('conv_wino', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')]
+                  if k != dom and k in ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')]
         if a.layers:
             agg = {}
             for name, kern, ms_, fl_, by_ in rows:

@@ -14,9 +14,6 @@ echo "== pytest -m gpu"
 timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider -rx --durations=10 > $OUT/pytest_gpu.log 2>&1
 echo "pytest exit $?" | tee -a $OUT/pytest_gpu.log
 grep -E "passed|failed|FAILED|Error" $OUT/pytest_gpu.log | tail -15
-echo "== bench"
-timeout 900 python bench.py --gpus 1 --steps 10 --warmup 3 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
-echo "bench exit $?"; cat $OUT/bench.json
 echo "== rocprofv3 kernel-trace --stats"
 cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o hp3d -- python $R/bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path --option streams=1 > $R/$OUT/prof_bench.json 2> $R/$OUT/prof_stderr.txt
 echo "rocprof exit $?"
@@ -26,4 +23,11 @@ if [ -n "$PMC" ]; then
     echo "pmc $C exit $?"
   done
 fi
-cd $R; find $OUT -name "*.csv" | head -20
+cd $R
+# the PMC passes feed bench.py's roofline.traffic through profiles/<family>_traffic.json: summarise them here (box-local copy of
+# profiles/; the committed files are regenerated from the merged gpurun_out/ by the same script), then take the bench line
+python scripts/summarize_prof.py $OUT $TAG > /dev/null 2>&1
+echo "== bench"
+timeout 900 python bench.py --gpus 1 --steps 10 --warmup 3 --layers > $OUT/bench.json 2> $OUT/bench_layers.txt
+echo "bench exit $?"; cat $OUT/bench.json
+find $OUT -name "*.csv" | head -20

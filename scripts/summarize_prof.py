@@ -15,6 +15,8 @@ from collections import defaultdict
 
 
 def _tree_id():
+    if os.environ.get('HP3D_TREE_ID'):
+        return os.environ['HP3D_TREE_ID']
     try:
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,6 +30,8 @@ def family(name):
         return 'conv_wino'
     if 'conv_wino2_kernel' in name:
         return 'conv_wino2'
+    if 'conv_wino4_kernel' in name:
+        return 'conv_wino4'
     if 'lift_fused_kernel' in name:
         return 'lift_fused'
     if 'conv_mfma_kernel' in name:
@@ -81,6 +85,12 @@ def main():
             bench = json.loads(open(os.path.join(src, 'bench.json')).read().strip().splitlines()[-1])
         except Exception:
             pass
+    wl_src = bench
+    if not wl_src and os.path.exists(os.path.join(src, 'prof_bench.json')):      # (run before the bench line exists: the profiled command's own line)
+        try:
+            wl_src = json.loads(open(os.path.join(src, 'prof_bench.json')).read().strip().splitlines()[-1])
+        except Exception:
+            wl_src = {}
     lines = ['# rocprofv3 summary %s' % tag, '',
              'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path --option streams=1`',
              '(one HIP stream, so that kernel durations are not inflated by the overlap the default two-stream mode is there to create;',
@@ -100,16 +110,16 @@ def main():
                   '(avg launch %.4f ms from HIP events; rocprof avg for that family above must agree)'
                   % (bench['value'], bench['unit'], bench['ms_per_step'], r.get('kernel'), r.get('achieved', 0), r.get('peak', 0),
                      r.get('unit'), r.get('frac', 0), r.get('avg_launch_ms', 0))]
-        for kf in ('conv_wino', 'conv_mfma'):
-            if kf in fetch and fetch[kf][1]:
-                rdb = 2.0 * fetch[kf][0] * 1024 / fetch[kf][1]
-                wtb = write[kf][0] * 1024 / write[kf][1] if write[kf][1] else 0
-                lines.append('%s HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (kf, rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
-                json.dump({"kernel": kf, "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
-                           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
-                           "stamp": "profile tag %s, summarised %s, tree %s" % (tag, __import__('datetime').date.today().isoformat(), _tree_id()),
-                           "workload": bench.get('config', {}).get('workload'), "dtype": bench.get('dtype', 'f32')},
-                          open(os.path.join(dst, kf + '_traffic.json'), 'w'), indent=1)
+    for kf in ('conv_wino4', 'conv_wino', 'conv_mfma'):
+        if wl_src and kf in fetch and fetch[kf][1]:
+            rdb = 2.0 * fetch[kf][0] * 1024 / fetch[kf][1]
+            wtb = write[kf][0] * 1024 / write[kf][1] if write[kf][1] else 0
+            lines.append('%s HBM traffic per launch (PMC): %.1f MB read + %.1f MB write = %.1f MB' % (kf, rdb / 1e6, wtb / 1e6, (rdb + wtb) / 1e6))
+            json.dump({"kernel": kf, "hbm_bytes_per_launch": rdb + wtb, "read_bytes": rdb, "write_bytes": wtb,
+                       "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE x2 per MI355X_MICROARCH.md, profile tag " + tag,
+                       "stamp": "profile tag %s, summarised %s, tree %s" % (tag, __import__('datetime').date.today().isoformat(), _tree_id()),
+                       "workload": wl_src.get('config', {}).get('workload'), "dtype": wl_src.get('dtype', 'f32')},
+                      open(os.path.join(dst, kf + '_traffic.json'), 'w'), indent=1)
     open(os.path.join(dst, tag + '_summary.md'), 'w').write('\n'.join(lines) + '\n')
     print('\n'.join(lines))
 

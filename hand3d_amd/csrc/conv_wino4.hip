@@ -400,26 +400,41 @@ void wino4_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_p
     const int nsub = k == 7 ? 9 : 1;
     const int nst = nsub * cin_pad / 16, CO16 = cout_pad / 16;
     memset(dst, 0, sizeof(float) * wino4_packed_floats(k, cin_pad, cout_pad));
+    // one (16-cout block, channel quad) at a time: its 36 x 64 transformed values are 36 contiguous 256-byte runs of the packed array
+    // (the plane-innermost order of the first version scattered every store over 36 cache lines: 60 s for the full weight set)
+    float blk[W4_NP][64];
     for (int sub = 0; sub < nsub; ++sub) {
         const int u0 = k == 7 ? 3 * (sub / 3) : 0, v0 = k == 7 ? 3 * (sub % 3) : 0;
-        for (int e_ = 0; e_ < cin_pad; ++e_) {
-            const int rc = chan_map ? chan_map[e_] : (e_ < Cin ? e_ : -1);
-            if (rc < 0) continue;
-            const int vc = sub * cin_pad + e_;
-            const int st = vc >> 4, q = (vc >> 2) & 3, e = vc & 3;
-            for (int co = 0; co < Cout; ++co) {
-                double w3[3][3];
-                for (int r = 0; r < 3; ++r)
-                    for (int c = 0; c < 3; ++c)
-                        w3[r][c] = (u0 + r < k && v0 + c < k) ? (double)g_hwio[((size_t)((u0 + r) * k + (v0 + c)) * Cin + rc) * Cout + co] : 0.0;
-                for (int a = 0; a < 6; ++a) {
-                    double ga[3];
-                    for (int c = 0; c < 3; ++c) ga[c] = G[a][0] * w3[0][c] + G[a][1] * w3[1][c] + G[a][2] * w3[2][c];
-                    for (int b = 0; b < 6; ++b) {
-                        const double s = ga[0] * G[b][0] + ga[1] * G[b][1] + ga[2] * G[b][2];
-                        dst[((((size_t)(a * 6 + b) * nst + st) * CO16 + (co >> 4)) * 4 + q) * 64 + (co & 15) * 4 + e] = (float)s;
+        for (int eq = 0; eq < cin_pad; eq += 4) {
+            int rc[4];
+            bool any = false;
+            for (int e = 0; e < 4; ++e) {
+                rc[e] = chan_map ? chan_map[eq + e] : (eq + e < Cin ? eq + e : -1);
+                any |= rc[e] >= 0;
+            }
+            if (!any) continue;
+            const int vc = sub * cin_pad + eq;
+            const int st = vc >> 4, q = (vc >> 2) & 3;
+            for (int c16 = 0; c16 < (Cout + 15) / 16; ++c16) {
+                memset(blk, 0, sizeof(blk));
+                for (int n = 0; n < 16; ++n) {
+                    const int co = 16 * c16 + n;
+                    if (co >= Cout) break;
+                    for (int e = 0; e < 4; ++e) {
+                        if (rc[e] < 0) continue;
+                        double w3[3][3];
+                        for (int r = 0; r < 3; ++r)
+                            for (int c = 0; c < 3; ++c)
+                                w3[r][c] = (u0 + r < k && v0 + c < k) ? (double)g_hwio[((size_t)((u0 + r) * k + (v0 + c)) * Cin + rc[e]) * Cout + co] : 0.0;
+                        for (int a = 0; a < 6; ++a) {
+                            double ga[3];
+                            for (int c = 0; c < 3; ++c) ga[c] = G[a][0] * w3[0][c] + G[a][1] * w3[1][c] + G[a][2] * w3[2][c];
+                            for (int b = 0; b < 6; ++b) blk[a * 6 + b][n * 4 + e] = (float)(ga[0] * G[b][0] + ga[1] * G[b][1] + ga[2] * G[b][2]);
+                        }
                     }
                 }
+                for (int pl = 0; pl < W4_NP; ++pl)
+                    memcpy(dst + ((((size_t)pl * nst + st) * CO16 + c16) * 4 + q) * 64, blk[pl], sizeof(blk[pl]));
             }
         }
     }

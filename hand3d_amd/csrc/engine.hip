@@ -10,6 +10,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <thread>
+#include <chrono>
+#include <atomic>
+#include <functional>
 #include <string>
 #include <vector>
 #ifndef HP3D_EMU
@@ -1544,33 +1548,69 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     if (!ctx) return HP3D_ERR_ARG;
     if (dtype != 0 && dtype != 1) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "dtype must be 0 (f32) or 1 (f16 trunks)");
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    const bool pack_timing = getenv("HP3D_PACK_TIMING") != nullptr;      // diagnostics: host seconds of the phases below on stderr
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char* what) {
+        if (pack_timing) fprintf(stderr, "hp3d_finalize_weights: %-28s %.2f s\n", what, now() - t_mark);
+        t_mark = now();
+    };
+    // staging: the packed blob is assembled on the host and uploaded once.  (The CPU interpreter's "device" memory IS host memory: it
+    // packs straight into the blob -- copying 1.3 GB once more costs tens of seconds in the sandboxes the CPU suite runs in.)
+#ifdef HP3D_EMU
+    if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
+    memset(ctx->blob, 0, sizeof(float) * ctx->T.blob_floats);
+    struct { float* p; float* data() { return p; } float& operator[](size_t i) { return p[i]; } } host{ctx->blob};
+#else
     std::vector<float> host(ctx->T.blob_floats, 0.f);
+#endif
+    lap("blob allocation");
     int have = 0, partial = 0, bn_ok = 0;
     auto mark = [&](int net, bool present) {
         if (present) have |= net; else partial |= net;
     };
+    // the convolution layers pack into disjoint regions of the blob: one task per layer, run on a few host threads (the 36-plane
+    // F(4x4,3x3) copies made this 40 s on one thread)
+    std::vector<std::function<void()>> pack_tasks;
     for (const ConvL& l : ctx->T.conv) {
         const HostVar *w = nullptr, *b = nullptr;
         const bool ok = find_var(ctx, l.name + "/weights", &w) == 0 && find_var(ctx, l.name + "/biases", &b) == 0;
         mark(l.net, ok);
-        if (ok) pack_conv(l, w->data.data(), b->data.data(), host.data());
-        if (ok && l.raw_off)          // lift_fused.hip: [cout block of 64][cin4][tap][64], zero rows / columns as padding
-            for (int t = 0; t < 9; ++t)
-                for (int c = 0; c < l.cin; ++c)
-                    for (int co = 0; co < l.cout; ++co)
-                        host[l.raw_off + (((size_t)(co >> 6) * l.cin4 + c) * 9 + t) * 64 + (co & 63)] = w->data[((size_t)t * l.cin + c) * l.cout + co];
-        if (ok && l.ww_off) {      // U = G g G^T in the Winograd kernel's fragment order
-            std::vector<int> cmap(l.cin_pad, -1);
-            for (int e = 0; e < l.cin_pad; ++e) {
-                if (l.mode == 0) cmap[e] = e < l.cin ? e : -1;
-                else if (e < 128) cmap[e] = 21 + e;            // concat buffer [encoding | scoremap | 0] vs reference [scoremap, encoding]
-                else if (e < 149) cmap[e] = e - 128;
+        if (!ok) continue;
+        const ConvL* lp = &l;
+        float* hp = host.data();
+        pack_tasks.push_back([lp, w, b, hp]() {
+            const ConvL& l = *lp;
+            pack_conv(l, w->data.data(), b->data.data(), hp);
+            if (l.raw_off)          // lift_fused.hip: [cout block of 64][cin4][tap][64], zero rows / columns as padding
+                for (int t = 0; t < 9; ++t)
+                    for (int c = 0; c < l.cin; ++c)
+                        for (int co = 0; co < l.cout; ++co)
+                            hp[l.raw_off + (((size_t)(co >> 6) * l.cin4 + c) * 9 + t) * 64 + (co & 63)] = w->data[((size_t)t * l.cin + c) * l.cout + co];
+            if (l.ww_off) {      // U = G g G^T in the Winograd kernels' fragment orders
+                std::vector<int> cmap(l.cin_pad, -1);
+                for (int e = 0; e < l.cin_pad; ++e) {
+                    if (l.mode == 0) cmap[e] = e < l.cin ? e : -1;
+                    else if (e < 128) cmap[e] = 21 + e;            // concat buffer [encoding | scoremap | 0] vs reference [scoremap, encoding]
+                    else if (e < 149) cmap[e] = e - 128;
+                }
+                wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww_off);
+                wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww2_off);
+                if (l.ww4_off) wino4_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww4_off);
             }
-            wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww_off);
-            wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww2_off);
-            if (l.ww4_off) wino4_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), host.data() + l.ww4_off);
-        }
+        });
     }
+    {
+        std::atomic<size_t> next{0};
+        auto worker = [&]() { for (size_t i; (i = next.fetch_add(1)) < pack_tasks.size();) pack_tasks[i](); };
+        unsigned nthr = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+        nthr = (unsigned)std::min<size_t>(nthr, pack_tasks.size());
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < nthr; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto& t : pool) t.join();
+    }
+    lap("conv layers (threads)");
     for (const FcL& l : ctx->T.fc) {
         if (l.name == "ViewpointNet/fc_vp_u") {
             const HostVar *w[3], *b[3];
@@ -1604,8 +1644,12 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     }
     const int bad = have & partial & (NET_SEG | NET_POSE | NET_PRIOR | NET_VP);
     if (bad) HP3D_FAIL(ctx, HP3D_ERR_WEIGHTS, "incomplete variable set for network mask %d", bad);
+    lap("fc layers");
+#ifndef HP3D_EMU
     if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
     HIPCHK(ctx, hipMemcpy(ctx->blob, host.data(), sizeof(float) * ctx->T.blob_floats, hipMemcpyHostToDevice));
+#endif
+    lap("blob upload");
     ctx->nets = have & ~partial;
     if (bn_ok == 2) ctx->nets |= NET_BOTTLENECK;
     ctx->prec = dtype;

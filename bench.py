@@ -186,7 +186,7 @@ def self_launch(a):
         # rank 0's stdout carries the ONE JSON line; whatever another rank prints goes to stderr
         procs.append(subprocess.Popen([sys.executable, entry] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = b''
+    out0, got0 = b'', False
     rcs = [None] * a.gpus
     first_fail = None
     try:
@@ -200,7 +200,7 @@ def self_launch(a):
             if rcs[0] is None:
                 try:                                    # drain rank 0's pipe while waiting (one JSON line: small)
                     o, _ = procs[0].communicate(timeout=0.2)
-                    out0 += o or b''
+                    out0, got0 = o or b'', True           # a communicate() that returns has ALL of rank 0's output
                 except subprocess.TimeoutExpired:
                     pass
             else:
@@ -214,10 +214,13 @@ def self_launch(a):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    if procs[0].stdout is not None:
+    # (a communicate() that timed out keeps what it had read inside the Popen object: only another communicate() returns it --
+    #  reading procs[0].stdout directly lost the line whenever rank 0 exited between two polls)
+    if not got0:
         try:
-            out0 += procs[0].stdout.read() or b''
-        except (OSError, ValueError):
+            o, _ = procs[0].communicate(timeout=30)
+            out0 = o or b''
+        except (OSError, ValueError, subprocess.TimeoutExpired):
             pass
     sys.stdout.write(out0.decode(errors='replace'))
     sys.stdout.flush()

@@ -70,7 +70,10 @@ constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: th
                                                    // 36 / W4_WPP planes.  Loads return in issue order, so a weight fragment issued behind a burst of
                                                    // 36 x 4 waves window loads waits for the whole burst to pass the CU's one address unit
                                                    // (measured: the wave stalled at plane 9 of every step, 25 % of the kernel's time)
-constexpr int W4_TRANSFORM_AT = 29;                // the plane under which the next step's windows are transformed
+#ifndef HP3D_W4_TAT
+#define HP3D_W4_TAT 29
+#endif
+constexpr int W4_TRANSFORM_AT = HP3D_W4_TAT;       // the plane under which the next step's windows are transformed
 
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
 __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }

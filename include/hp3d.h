@@ -65,7 +65,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            on two HIP streams (second arena, shared weights; fills the tail rounds of the persistent
  *                            kernels and the launch gaps).  auto = 2 from 16 images per call.  Results equal "1" to
  *                            rounding (images are independent; a half may take the small-batch kernel plan);
- *                            profiling / graph replay use one stream;
+ *                            profiling / graph replay use one stream.  The halves overlap on the device-pointer entry points
+ *                            (hp3d_infer_full_dev ...); with HOST output buffers the first half's pageable device->host
+ *                            copies block the host before the second half is enqueued;
  *          "wino_splitk"  = "1" (default) | "0": Winograd layers whose work items under-fill the chip (small batches) split
  *                            their channel steps over up to 16 workgroups and sum float32 partials in a fixed order;
  *          "wino2"        = "auto" (default) | "0" | "1": which of the two float32 Winograd kernels a 3x3 / 7x7 layer takes when both

@@ -223,7 +223,10 @@ void conv_wino4_kernel(const ConvParams p) {
 
     f32x4 M[W4_NP][2];     // [plane][tile half]: rows = tiles 16 m + 4 (lane >> 4) + r, column = cout (lane & 15)
     f32x4 bq[W4_RING];
-    auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
+#ifndef HP3D_W4_BAUX
+#define HP3D_W4_BAUX 0           // cache policy of the weight-fragment loads (experiments: 16 = sc1, 2 = nt)
+#endif
+    auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_W4_BAUX ? HP3D_BUFFER_LOAD16_AUX(wrsrc, voff, soff, HP3D_W4_BAUX) : HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
     const int va_lane = (ln * W4_CK + ((lq ^ w4_swz(ln)) * 4)) * 4;
     int ab0 = 0, ab1 = 0;
     f32x4 af[W4_ADEPTH][2];

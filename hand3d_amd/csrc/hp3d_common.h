@@ -158,6 +158,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 8 B per lane (same addressing / range check)
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) \
     __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 0))
+// 16 B per lane with an explicit cache-policy immediate (bit 0 sc0, bit 1 nt, bit 4 sc1): tuning experiments only
+#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), (aux)))
 // 8 B per lane, non-temporal (nt): a streaming read that should not displace other lines of the L2
 #define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) \
     __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 2))
@@ -190,6 +193,7 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
 #define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
+#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))

@@ -75,6 +75,7 @@ static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
 }
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     float v = 0.f;
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy(&v, r.base + voff + soff, 4);

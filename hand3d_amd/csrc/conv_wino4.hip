@@ -75,6 +75,22 @@ constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: th
 #endif
 constexpr int W4_TRANSFORM_AT = HP3D_W4_TAT;       // the plane under which the next step's windows are transformed
 
+// issue order of the 36 window elements.  Neighbouring tiles' windows overlap by two rows / columns, so (r >= 4, c) is the pixel another
+// lane loads as (r - 4, c) and (r, c >= 4) the one loaded as (r, c - 4): in row-major order the two requests for a line follow each
+// other within two planes, i.e. the second one hits a line whose fill is still pending.  HP3D_W4_ISSUE = 1 walks the window in 2x2
+// blocks ordered so that every such pair lies at least six planes apart.
+#ifndef HP3D_W4_ISSUE
+#define HP3D_W4_ISSUE 0
+#endif
+__host__ __device__ constexpr int w4_issue_order(int k) {
+#if HP3D_W4_ISSUE
+    constexpr int blk[9][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {0, 2}, {2, 0}, {2, 1}, {1, 2}, {2, 2}};
+    return (2 * blk[k / 4][0] + ((k >> 1) & 1)) * 6 + 2 * blk[k / 4][1] + (k & 1);
+#else
+    return k;
+#endif
+}
+
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
 __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }
 
@@ -318,8 +334,10 @@ void conv_wino4_kernel(const ConvParams p) {
                 else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
                 if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
 #pragma unroll
-                    for (int j = 0; j < W4_WPP; ++j)          // (indices are constants once the plane loop is unrolled)
-                        d[pl * W4_WPP + j] = W4_WLOAD(irsrc, (int)((unsigned)ro[(pl * W4_WPP + j) / 6] + (unsigned)co[(pl * W4_WPP + j) % 6]), wsoff);
+                    for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
+                        const int e = w4_issue_order(pl * W4_WPP + j);
+                        d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
+                    }
                 }
                 if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) transform_commit(cur ^ 1);
             }

@@ -13,7 +13,13 @@ the TensorFlow kernels (conv2d, resize_bilinear, crop_and_resize, dilation2d, so
 the functions of oracle/tf_ops.py and are cross-checked separately
 (tests/test_oracle_ops.py).
 
-Execution model: eager.  A "tensor" is an ndarray subclass that also answers get_shape()/set_shape();
+Execution model: eager by default; since round 3 also a GRAPH facade (bottom of this file): `tf.placeholder` starts a trace,
+every op applied to a traced tensor is recorded while it is evaluated on zero-filled stand-in data (which gives the static
+shapes the reference's Python asks for), variables without a value yet become variable nodes, and `Session.run(fetches,
+feed_dict)` replays the recorded ops on the fed values -- so `scripts/make_tf_fixtures.py`'s real-TensorFlow branch (graph on
+placeholders, `net.init(sess)` AFTER the graph is built, `sess.run`) executes here too.
+
+Eager model: a "tensor" is an ndarray subclass that also answers get_shape()/set_shape();
 variables come from a process-global store keyed by their full variable-scope name (filled by
 tf.contrib.framework.assign_from_values, i.e. by the reference's own `init()`), so `init()` has to be
 called BEFORE `inference()` here (TF builds the graph first and assigns afterwards; the order is the
@@ -59,7 +65,42 @@ class _Shape(object):
 
 
 class Tensor(np.ndarray):
-    """ndarray + the two shape methods the reference calls on tf.Tensor."""
+    """ndarray + the two shape methods the reference calls on tf.Tensor (+ the graph facade's node id: None = not traced)."""
+    _nid = None
+
+    def __hash__(self):                      # tf.Tensor is hashable by identity (feed_dict keys)
+        return id(self)
+
+    def __array_finalize__(self, obj):
+        self._nid = None                     # views / results are new tensors: only the recorder tags them
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        # Python operators on tensors (a * b, -a, a < b ...) arrive here.  Default NumPy behaviour, plus a graph node when traced.
+        raw = tuple(i.view(np.ndarray) if isinstance(i, Tensor) else i for i in inputs)
+        if 'out' in kwargs:
+            kwargs['out'] = tuple(o.view(np.ndarray) if isinstance(o, Tensor) else o for o in kwargs['out'])
+        res = getattr(ufunc, method)(*raw, **kwargs)
+        if isinstance(res, tuple):
+            out = tuple(r.view(Tensor) if isinstance(r, np.ndarray) else r for r in res)
+        elif isinstance(res, np.ndarray):
+            out = res.view(Tensor)
+        elif isinstance(res, np.generic) and method == '__call__':
+            out = np.asarray(res).view(Tensor)          # 0-d tensors stay tensors under element-wise ops
+        else:
+            out = res
+        if _graph['on'] and not _graph['busy'] and _any_traced(inputs):
+            kw = dict(kwargs)
+            _record(lambda *a: getattr(ufunc, method)(*a, **kw), inputs, {}, out)
+        return out
+
+    def __getitem__(self, idx):
+        out = super(Tensor, self).__getitem__(idx)
+        if _graph['on'] and not _graph['busy'] and (self._nid is not None or _any_traced(idx)):
+            if not isinstance(out, np.ndarray):
+                out = np.asarray(out).view(Tensor)
+            _record(lambda a, i: np.ndarray.__getitem__(a.view(np.ndarray), i).view(Tensor) if isinstance(a, np.ndarray) else a[i],
+                    (self, idx), {}, out)
+        return out
 
     def get_shape(self):
         return _Shape(self.shape)
@@ -102,7 +143,13 @@ def constant(value, dtype=None, shape=None, name=None):
 
 
 def placeholder(dtype, shape=None, name=None):
-    raise NotImplementedError("the NumPy shim is eager: call the network methods on arrays instead of placeholders")
+    """Graph facade: a zero-filled stand-in of the (fully known) shape; switches the recorder on."""
+    assert shape is not None and all(d is not None for d in shape), "the graph facade needs fully defined placeholder shapes"
+    t = np.zeros([int(d) for d in shape], dtype=dtype).view(Tensor)
+    _graph['on'] = True
+    t._nid = _new_id()
+    _graph['nodes'].append({'kind': 'placeholder', 'nid': t._nid, 'dtype': np.dtype(dtype)})
+    return t
 
 
 # ----------------------------------------------------------------------------- scopes and variables
@@ -113,6 +160,8 @@ _variables = {}            # full name (no ':0') -> float32 ndarray
 def reset_default_graph():
     del _scope_stack[:]
     _variables.clear()
+    _graph.update(on=False, busy=0, next=0)
+    del _graph['nodes'][:]
 
 
 @contextlib.contextmanager
@@ -135,6 +184,13 @@ def constant_initializer(value=0.0, dtype=None):
 
 def get_variable(name, shape=None, dtype=None, initializer=None, trainable=True, collections=None, **kw):
     full = '/'.join(_scope_stack + [name])
+    if full not in _variables and _graph['on'] and shape is not None:
+        # graph facade: TF builds the graph first and assigns afterwards (net.init(sess) after inference()): a variable node
+        # whose value is read from the store when Session.run replays the graph
+        t = np.zeros([int(s) for s in shape], dtype=np.float32).view(Tensor)
+        t._nid = _new_id()
+        _graph['nodes'].append({'kind': 'variable', 'nid': t._nid, 'name': full, 'shape': [int(s) for s in shape]})
+        return t
     if full not in _variables:
         raise KeyError("variable '%s' has no value: call the network's init() with weight files that contain it "
                        "before inference() (eager shim)" % full)
@@ -151,7 +207,8 @@ def global_variables_initializer():
 
 def check_numerics(tensor, message, name=None):
     a = _a(tensor)
-    if not np.all(np.isfinite(a)):
+    tracing = _graph['on'] and not _graph['busy'] and _any_traced(tensor)
+    if not tracing and not np.all(np.isfinite(a)):
         raise FloatingPointError(message + ' : Tensor had NaN / Inf values')
     return _t(a)
 
@@ -207,6 +264,9 @@ class Session(object):
         pass
 
     def run(self, fetches, feed_dict=None):
+        if _graph['on'] and _any_traced(fetches):
+            return _replay(fetches, feed_dict or {})
+
         def one(f):
             if isinstance(f, tuple) and len(f) == 2 and f[0] == '__assign__':
                 for k, v in f[1].items():
@@ -348,6 +408,25 @@ def one_hot(indices, depth, on_value=1.0, off_value=0.0, axis=-1, dtype=np.float
 def cond(pred, fn1=None, fn2=None, name=None, true_fn=None, false_fn=None):
     fn1 = fn1 if fn1 is not None else true_fn
     fn2 = fn2 if fn2 is not None else false_fn
+    if _graph['on'] and not _graph['busy'] and _any_traced(pred):
+        # graph facade: both branches are traced (TF builds both sub-graphs too) and a select node picks at run time; a branch the
+        # shim cannot evaluate (training-only ops) becomes an error that fires only if the run selects it
+        def branch(fn):
+            try:
+                return fn()
+            except NotImplementedError as e:
+                return e
+        a, b = branch(fn1), branch(fn2)
+        good = a if not isinstance(a, Exception) else b
+        out = _t(np.array(_a(good)))
+
+        def select(p, x, y):
+            v = x if np.bool_(_a(p)) else y
+            if isinstance(v, Exception):
+                raise v
+            return _t(_a(v))
+        _record(select, (pred, a, b), {}, out)
+        return out
     return _t(_a(fn1() if np.bool_(_a(pred)) else fn2()))
 
 
@@ -560,3 +639,138 @@ class _Train(object):
 
 
 train = _Train()
+
+
+# ----------------------------------------------------------------------------- graph facade (trace + replay)
+# State: `on` after the first tf.placeholder (until reset_default_graph), `busy` > 0 inside a recorded op or a replay (nested
+# shim calls are part of the op that is being recorded, not nodes of their own), `nodes` in creation order.
+_graph = {'on': False, 'busy': 0, 'next': 0, 'nodes': []}
+
+
+def _new_id():
+    _graph['next'] += 1
+    return _graph['next']
+
+
+def _any_traced(obj):
+    if isinstance(obj, Tensor):
+        return obj._nid is not None
+    if isinstance(obj, (list, tuple)):
+        return any(_any_traced(o) for o in obj)
+    if isinstance(obj, dict):
+        return any(_any_traced(o) for o in obj.values())
+    return False
+
+
+def _tag(out):
+    """Node ids for the tensors of an op's result (same nesting); a tensor that already carries one is an input passed through."""
+    if isinstance(out, Tensor):
+        if out._nid is None:
+            out._nid = _new_id()
+        return ('t', out._nid)
+    if isinstance(out, (list, tuple)):
+        return ('l', [_tag(o) for o in out])
+    if isinstance(out, dict):
+        return ('d', {k: _tag(v) for k, v in out.items()})
+    return ('c', None)
+
+
+def _record(fn, args, kw, out):
+    _graph['nodes'].append({'kind': 'op', 'fn': fn, 'args': args, 'kw': kw, 'out': _tag(out)})
+
+
+def _traced(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def op(*args, **kw):
+        if not _graph['on'] or _graph['busy']:
+            return fn(*args, **kw)
+        _graph['busy'] += 1
+        try:
+            out = fn(*args, **kw)
+        finally:
+            _graph['busy'] -= 1
+        if _any_traced(args) or _any_traced(kw):
+            _record(fn, args, kw, out)
+        return out
+    return op
+
+
+def _replay(fetches, feed):
+    env = {}
+    for ph, val in feed.items():
+        assert isinstance(ph, Tensor) and ph._nid is not None, "feed_dict keys must be placeholders of this graph"
+        assert tuple(np.shape(val)) == ph.shape, "fed shape %r, placeholder shape %r" % (np.shape(val), ph.shape)
+        env[ph._nid] = np.asarray(val, dtype=ph.dtype).view(Tensor)
+
+    def subst(o):
+        if isinstance(o, Tensor) and o._nid is not None:
+            if o._nid not in env:
+                raise KeyError("graph facade: a placeholder the fetches depend on was not fed")
+            return env[o._nid]
+        if isinstance(o, list):
+            return [subst(v) for v in o]
+        if isinstance(o, tuple):
+            return tuple(subst(v) for v in o)
+        if isinstance(o, dict):
+            return {k: subst(v) for k, v in o.items()}
+        return o
+
+    def bind(tag, val):
+        kind, what = tag
+        if kind == 't':
+            if what not in env:                       # (an input passed through keeps its value)
+                env[what] = val if isinstance(val, Tensor) else np.asarray(val).view(Tensor)
+        elif kind == 'l':
+            for t, v in zip(what, val):
+                bind(t, v)
+        elif kind == 'd':
+            for k, t in what.items():
+                bind(t, val[k])
+
+    _graph['busy'] += 1
+    try:
+        for n in _graph['nodes']:
+            if n['kind'] == 'variable':
+                if n['name'] not in _variables:
+                    raise KeyError("variable '%s' has no value: net.init(sess, ...) must run before sess.run" % n['name'])
+                v = _variables[n['name']]
+                assert list(v.shape) == n['shape'], "variable %s: stored shape %r, graph shape %r" % (n['name'], v.shape, n['shape'])
+                env[n['nid']] = _t(v)
+            elif n['kind'] == 'op':
+                try:
+                    args, kw = subst(n['args']), subst(n['kw'])
+                except KeyError:
+                    continue                          # depends on a placeholder that was not fed: only an error if fetched
+                bind(n['out'], n['fn'](*args, **kw))
+
+        def fetch(f):
+            if isinstance(f, dict):
+                return {k: fetch(v) for k, v in f.items()}
+            if isinstance(f, (list, tuple)):
+                return [fetch(v) for v in f]
+            if f is None:
+                return None
+            return np.asarray(subst(f)).view(np.ndarray)
+        return fetch(fetches)
+    finally:
+        _graph['busy'] -= 1
+
+
+def _install_tracing():
+    import types
+    skip = {'placeholder', 'cond', 'get_variable', 'variable_scope', 'name_scope', 'reset_default_graph', 'constant_initializer',
+            'global_variables_initializer', 'check_numerics'}
+    g = globals()
+    for name, f in list(g.items()):
+        if isinstance(f, types.FunctionType) and not name.startswith('_') and name not in skip and f.__module__ == __name__:
+            g[name] = _traced(f)
+    g['check_numerics'] = _traced(g['check_numerics'])
+    for cls in (_NN, _Image):
+        for name, f in list(vars(cls).items()):
+            if isinstance(f, staticmethod):
+                setattr(cls, name, staticmethod(_traced(f.__func__)))
+
+
+_install_tracing()

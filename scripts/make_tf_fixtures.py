@@ -13,7 +13,9 @@ Two ways to run it -- the SAME code path either way:
     the one gap left in the parity chain: the arithmetic inside TensorFlow's kernels.
 
   * in the build container, through scripts/make_ref_fixtures.py, with oracle/tfshim standing in for tensorflow (eager
-    NumPy) -> tests/golden/ref_*.npz.  This is also what keeps this script exercised where no TensorFlow exists.
+    NumPy) -> tests/golden/ref_*.npz.  This is also what keeps this script exercised where no TensorFlow exists -- both of its
+    branches: `eager=False` over the stand-in's graph facade runs the placeholder / sess.run code below unchanged and must reproduce
+    the eager files bit for bit (tests/test_reference_pin.py).
 
 With real TF the graph is built on placeholders, `net.init(sess)` assigns the pickled weights, and `sess.run` evaluates;
 with the eager stand-in `init` runs first and the network methods are called on the arrays directly.

@@ -370,3 +370,37 @@ def test_stb_reader_equals_reference_reader(ref, tmp_path, monkeypatch):
                     assert np.array_equal(p, v), k
                 else:
                     assert np.allclose(p, v, rtol=1e-6, atol=2e-7), k
+
+
+def test_real_tensorflow_branch_of_the_fixture_dump_runs_on_the_graph_facade(ref, tmp_path, monkeypatch):
+    """scripts/make_tf_fixtures.py has two branches: the eager one that wrote tests/golden/ref_*.npz, and the one a TensorFlow box
+    would run -- graph on `tf.placeholder`s, `sess.run(tf.global_variables_initializer())`, `net.init(sess, ...)` AFTER the graph is
+    built, `sess.run(fetches, feed_dict)` ("its graph-mode branch has never executed anywhere").  oracle/tfshim's graph
+    facade (trace on stand-in data, variable nodes, both `tf.cond` branches, replay on the fed values) executes exactly that branch
+    over the reference's unmodified modules, and every array of every file it writes equals the committed eager fixture bit for bit."""
+    import glob
+    import sys
+    scripts = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'scripts')
+    monkeypatch.syspath_prepend(scripts)
+    import make_ref_fixtures
+    import make_tf_fixtures
+    inputs, out = tmp_path / 'inputs', tmp_path / 'out'
+    os.makedirs(out)
+    make_ref_fixtures.export_inputs(str(inputs))
+    monkeypatch.setattr(G, 'EMPTY_REDUCE', G.EMPTY_REDUCE)          # (the dump switches it per case; restored afterwards)
+    try:
+        make_tf_fixtures.main(['--inputs', str(inputs), '--out', str(out), '--prefix', 'graph_'], tf=ref.tf, eager=False,
+                              mods=(ref.ColorHandPose3DNetwork, ref.PosePriorNetwork, ref.general),
+                              set_empty_reduce=lambda rid: setattr(G, 'EMPTY_REDUCE', rid))
+    finally:
+        ref.tf.reset_default_graph()
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    files = sorted(glob.glob(str(out / 'graph_*.npz')))
+    assert len(files) == 5
+    for f in files:
+        a, b = np.load(f, allow_pickle=True), np.load(os.path.join(golden, 'ref_' + os.path.basename(f)[6:]), allow_pickle=True)
+        assert sorted(a.files) == sorted(b.files), os.path.basename(f)
+        for k in a.files:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (f, k)
+            assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == 'f'), (os.path.basename(f), k)
+    assert 'make_tf_fixtures' in sys.modules

@@ -954,8 +954,8 @@ int need_nets(hp3d_ctx* ctx, int mask) {
 }
 
 int check_img(hp3d_ctx* ctx, int B, int H, int W) {
-    if (B < 1 || H < 16 || W < 16 || (H % 8) || (W % 8))
-        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad shape B=%d H=%d W=%d (need B>=1, H,W multiples of 8, >=16)", B, H, W);
+    if (B < 1 || H < 16 || W < 16)
+        HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad shape B=%d H=%d W=%d (need B>=1, H,W >=16)", B, H, W);
     if ((size_t)3 * H * ((W + 31) / 32) * 4 > 160 * 1024 - 1024)
         HP3D_FAIL(ctx, HP3D_ERR_ARG, "image %dx%d too large for the in-LDS mask growth", H, W);
     return 0;

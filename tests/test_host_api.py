@@ -63,7 +63,7 @@ def test_error_behaviour(emu_engine, synth_weights):
     with pytest.raises(NotImplementedError):
         net.inference_pose2d(img, train=True)
     with pytest.raises(AssertionError):
-        net.inference_detection(np.zeros((1, 20, 24, 3), np.float32))     # H not a multiple of 8
+        net.inference_detection(np.zeros((1, 12, 24, 3), np.float32))     # H < 16
     with pytest.raises(AssertionError):
         emu_engine.set_weight('HandSegNet/conv1_1/weights', np.zeros((3, 3, 3, 63), np.float32))   # bad shape
     with pytest.raises(AssertionError):

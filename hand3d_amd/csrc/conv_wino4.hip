@@ -30,6 +30,9 @@
 #define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
 #endif
 
+#ifndef HP3D_W4_SYNC
+#define HP3D_W4_SYNC 0             // 0: one __syncthreads per step; 1: LDS-counter hand-off between the four waves (measured: -0.5 %, see below)
+#endif
 #ifndef HP3D_W4_ORDER
 #define HP3D_W4_ORDER 1            // 1: XCD-affine item order (conv3_2 -6 %), 0: cout-block-major like conv_wino.hip
 #endif
@@ -50,7 +53,7 @@ constexpr int W4_COUTS = 64;                       // output channels per item (
 constexpr int W4_NP = 36;                          // planes
 constexpr int W4_PLANE_FLOATS = W4_TILES * W4_CK;  // one plane of one V buffer: 2 KB
 constexpr int W4_VBUF_FLOATS = W4_NP * W4_PLANE_FLOATS;
-constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4;     // 2 V buffers + two tile tables = 147968 B
+constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4 + 16;     // 2 V buffers + two tile tables + two hand-off counters = 147984 B
 #ifndef HP3D_W4_RING
 #define HP3D_W4_RING 9
 #endif
@@ -122,6 +125,13 @@ void conv_wino4_kernel(const ConvParams p) {
     static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
     HP3D_DYN_SMEM(V);
     int* tinfo = (int*)(V + 2 * W4_VBUF_FLOATS);       // [parity][0..31] output offset of tile t (-1: none), [32..63] edge flags
+    // hand-off counters (HP3D_W4_SYNC): sync[0] += 1 per wave that has WRITTEN its share of the next step's V, sync[1] += 1 per wave
+    // that has finished READING the current step's V.  A step ends with "all four wrote" instead of a barrier -- the writes happen
+    // under plane 29, six planes before they are needed, so a wave that runs a little late no longer holds the other three -- and
+    // "all four read step g - 1" guards the buffer before step g's transform overwrites it.  Built because removing the barrier altogether
+    // (a timing ablation with wrong results) gained 10 %; measured: 2100 vs 2113 images/s for the barrier -- what the ablation gained was
+    // the waves drifting a whole step apart, which no correct hand-off allows.  Kept as a build knob, off.
+    int* sync = tinfo + 2 * 2 * W4_TILES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int ln = lane & 15, lq = lane >> 4;          // MFMA column (cout / tile in block) and k slot
@@ -282,8 +292,10 @@ void conv_wino4_kernel(const ConvParams p) {
 #pragma unroll
     for (int t = 0; t < W4_RING; ++t) b_fetch(t, wvoff, soff_of(t, s0));
     transform_commit(0);
+    if (HP3D_W4_SYNC && tid < 2) sync[tid] = 0;
     __syncthreads();
     int cur = 0;
+    int gstep = 0;                                     // steps this workgroup has completed (all items)
 
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0;
@@ -339,10 +351,20 @@ void conv_wino4_kernel(const ConvParams p) {
                         d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
                     }
                 }
-                if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) transform_commit(cur ^ 1);
+                if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) {
+                    if (HP3D_W4_SYNC) HP3D_LDS_WAIT_GE(sync + 1, 4 * gstep);       // V[cur ^ 1] was read in step gstep - 1: all four done?
+                    transform_commit(cur ^ 1);
+                    if (HP3D_W4_SYNC) HP3D_LDS_SIGNAL(sync + 0, lane);
+                }
             }
             HP3D_SCHED_BARRIER();
-            if (!(HP3D_W4_ABL & 4)) __syncthreads();             // V[cur^1] complete, V[cur] free
+            if (HP3D_W4_SYNC) {
+                HP3D_LDS_SIGNAL(sync + 1, lane);                                // this wave's reads of V[cur] are issued (LDS is in order)
+                HP3D_LDS_WAIT_GE(sync + 0, 4 * (gstep + 1));                    // V[cur ^ 1] complete?
+                ++gstep;
+            } else if (!(HP3D_W4_ABL & 4)) {
+                __syncthreads();             // V[cur^1] complete, V[cur] free
+            }
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };

@@ -112,6 +112,23 @@ static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
 #define HP3D_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define HP3D_TICKET_AGENT(ptr) __hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define HP3D_STORE_RELAXED_AGENT(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// Hand-off between the waves of ONE workgroup through a counter in LDS, instead of s_barrier: a producer wave adds 1 after its LDS
+// writes (or reads) -- the LDS unit executes a wave's instructions in issue order, so whoever sees the count sees them done -- and a
+// consumer polls until the count it needs is there.  Relaxed atomics + compiler barriers only: a C++ release / acquire at workgroup
+// scope would also drain vmcnt, i.e. the weight ring.
+#define HP3D_LDS_SIGNAL(ptr, lane)                                                                         \
+    do {                                                                                                   \
+        asm volatile("" ::: "memory");                                                                     \
+        if ((lane) == 0) (void)__hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
+        asm volatile("" ::: "memory");                                                                     \
+    } while (0)
+#define HP3D_LDS_WAIT_GE(ptr, target)                                                                      \
+    do {                                                                                                   \
+        asm volatile("" ::: "memory");                                                                     \
+        while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - (int)(target)) < 0) \
+            __builtin_amdgcn_s_sleep(1);                                                                   \
+        asm volatile("" ::: "memory");                                                                     \
+    } while (0)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)

@@ -94,6 +94,14 @@ int wave_rendezvous(WaveX& w, int lanes_in_wave) {
 
 }  // namespace
 
+// cooperative wait: lets the other fibers of the block run (polling loops on LDS counters)
+void hp3d_emu_yield() { yield_to_main(); }
+// all 64 lanes of the calling fiber's wave arrive before any continues (on the hardware a wave's lanes execute in lockstep)
+void hp3d_emu_wave_sync() {
+    WaveX& w = g_blk.waves[g_blk.cur->tid >> 6];
+    wave_rendezvous(w, 64);
+}
+
 void hp3d_emu_syncthreads() {
     const int gen = g_blk.bar_gen;
     g_blk.bar_count++;

@@ -119,6 +119,11 @@ void hp3d_emu_run(dim3 grid, dim3 block, size_t shmem, const std::function<void(
     hp3d_emu_run(grid, block, shmem, [=]() { kern(__VA_ARGS__); })
 
 void hp3d_emu_syncthreads();
+void hp3d_emu_yield();
+// LDS-counter hand-off inside a workgroup (conv_wino4.hip): one lane of a wave adds 1; a waiter lets the other fibers run until the count is reached
+void hp3d_emu_wave_sync();
+#define HP3D_LDS_SIGNAL(ptr, lane) do { hp3d_emu_wave_sync(); if ((lane) == 0) *(ptr) += 1; } while (0)       /* (a wave's lanes are fibers here) */
+#define HP3D_LDS_WAIT_GE(ptr, target) do { while ((int)(*(volatile int*)(ptr) - (int)(target)) < 0) hp3d_emu_yield(); } while (0)
 #define __syncthreads hp3d_emu_syncthreads
 f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
 #define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))

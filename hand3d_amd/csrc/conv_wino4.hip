@@ -4,9 +4,9 @@
 // stride-1 layers and the 7x7 layers of PoseNet2D, nets/ColorHandPose3DNetwork.py:170-219, as nine 3x3 blocks), with the
 // larger Winograd tile: a 6x6 input window gives 4x4 outputs through 36 element-wise products per (cin, cout) -- 2.25
 // multiply-adds per output instead of 4 (F(2x2,3x3)) or 9 (direct).  Float32 throughout; the transforms now multiply by
-// 2, 4, 5, 8 and the transformed filters by 1/4 .. 1/24, which costs 3.5x the rounding error of F(2x2,3x3) END TO END on
-// PoseNet2D (heat-maps 4.7e-6 against a gate of 1e-3, profiles/r03_tuning_notes.md section 5) -- the executor takes this kernel
-// only where that was measured (option "wino4").
+// 2, 4, 5, 8 and the transformed filters by 1/4 .. 1/24, which costs 3.5x the rounding error of F(2x2,3x3) END TO END
+// (heat-maps 6e-6 against a gate of 1e-3, 3-D keypoints 3e-6 against 1e-4: profiles/r03_tuning_notes.md sections 5 and 7, where the
+// effect on the thresholded hand mask is measured too).  The executor gives it every filled 3x3 / 7x7 trunk launch (option "wino4").
 //
 //   Y(4x4) = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A          d: 6x6 window, g: 3x3 filter, points {0, +-1, +-2, inf}
 //
@@ -14,11 +14,14 @@
 // couts in 16-channel steps, K order permuted so that A and B are one 16-byte access per four MFMAs, weights global ->
 // VGPR in fragment order) with 36 planes instead of 16:
 //   * 36 planes x 2 tile halves x 4 = 288 accumulators per lane -> one wave per SIMD (__launch_bounds__(256, 1): 512
-//     registers per lane, the compiler splits the accumulators over AGPRs and VGPRs);
+//     registers per lane); planes 0..31 are PINNED to the 256 AGPRs and planes 32..35 to arch VGPRs through the constraint of the
+//     inline-asm statement that holds a plane's eight MFMAs (left alone, hipcc moved ~10 tuples per step between the files);
 //   * V = B^T d B double buffered in LDS: 2 x 36 planes x 32 tiles x 16 channels = 147 KB;
 //   * loader thread = (tile, channel pair): 36 window loads of 8 bytes; the offsets are 6 row + 6 column terms (a row /
 //     column outside the image carries a constant that pushes the sum out of the buffer's range: reads as 0) added at
-//     issue time, not 36 registers;
+//     issue time, not 36 registers; the loads are spread two per plane over the first 18 planes of a step;
+//   * weights [36 planes][step][Cout/16][q][n][e] through a ring of 9 planes; work items in XCD-affine order (the cout blocks of a
+//     tile block run on one XCD, so its windows cross the fabric once per XCD);
 //   * a tile is 16 output pixels: the fused 2x2 max-pool takes four maxima per tile; ragged image edges (Ho, Wo not a
 //     multiple of 4) drop rows / columns through out-of-range store offsets.
 #include "hp3d_common.h"

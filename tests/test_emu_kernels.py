@@ -388,7 +388,11 @@ def test_winograd_two_workgroups_per_cu_kernel_on_interpreter(emu_engine, case):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 8, 12, 96, 128, 1, 3),
-                                  (1, 17, 21, 32, 64, 0, 3), (1, 12, 14, 32, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7), (3, 10, 6, 16, 64, 1, 3)],
+                                  (1, 17, 21, 32, 64, 0, 3), (1, 12, 14, 32, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7), (3, 10, 6, 16, 64, 1, 3),
+                                  # 8 tile blocks: the XCD-affine item order; one 16-channel step per item; three cout blocks; a pooled layer
+                                  # whose pooled extent is odd; a 7x7 layer whose channel split cuts through the nine blocks
+                                  (4, 32, 32, 32, 128, 0, 3), (1, 16, 16, 16, 64, 0, 3), (1, 20, 24, 64, 192, 0, 3), (1, 18, 22, 32, 64, 1, 3),
+                                  (1, 16, 16, 80, 64, 0, 7)],
                          ids=lambda c: "B%d_%dx%d_%d-%d_p%d_k%d" % c)
 def test_winograd_f4x4_kernel_on_interpreter(emu_engine, case):
     """conv_wino4.hip (option wino4 = 1) on the interpreter: F(4x4,3x3) with 36 planes -- 6x6 windows from row + column offset terms

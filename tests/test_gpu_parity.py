@@ -174,7 +174,9 @@ def test_conv_winograd_two_workgroups_per_cu_7x7(gpu_engine, case):
 
 W4_CASES = [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 17, 21, 32, 64, 0, 3), (1, 30, 40, 512, 512, 0, 3),
             (1, 32, 32, 256, 256, 0, 3), (2, 60, 80, 128, 256, 1, 3), (3, 10, 6, 16, 64, 1, 3), (16, 64, 64, 256, 256, 0, 3), (16, 128, 128, 128, 128, 1, 3),
-            (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7)]
+            (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7),
+            # one 16-channel step per item; three cout blocks; a pooled layer with an odd pooled extent; a 7x7 split that cuts through the nine blocks
+            (1, 16, 16, 16, 64, 0, 3), (1, 20, 24, 64, 192, 0, 3), (1, 18, 22, 32, 64, 1, 3), (1, 16, 16, 80, 64, 0, 7), (8, 64, 64, 64, 128, 0, 3)]
 
 
 @pytest.mark.parametrize("case", W4_CASES, ids=lambda c: "B%d_%dx%d_%d-%d_p%d_k%d" % c)

@@ -159,16 +159,19 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c) {
     // Products are exact in f32; accumulation is modelled in k order (the hardware's internal order is
     // not specified -- tests use tolerances that cover it).
     const int col = lane & 31, hi = lane >> 5;
+    float bf[16];                                  // this lane's B column, converted once (same values, same k order as before)
+    for (int h = 0; h < 2; ++h) {
+        _Float16 bh[8];
+        memcpy(bh, &w.b4[slot][col + 32 * h], 16);
+        for (int j = 0; j < 8; ++j) bf[8 * h + j] = (float)bh[j];
+    }
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        _Float16 ah[16];
+        memcpy(ah, &w.a4[slot][row], 16);
+        memcpy(ah + 8, &w.a4[slot][row + 32], 16);
         float d = c[r];
-        for (int k = 0; k < 16; ++k) {
-            f32x4 av = w.a4[slot][row + 32 * (k >> 3)], bv = w.b4[slot][col + 32 * (k >> 3)];
-            _Float16 ah[8], bh[8];
-            memcpy(ah, &av, 16);
-            memcpy(bh, &bv, 16);
-            d += (float)ah[k & 7] * (float)bh[k & 7];
-        }
+        for (int k = 0; k < 16; ++k) d += (float)ah[k] * bf[k];
         c[r] = d;
     }
     return c;

@@ -103,6 +103,7 @@ def test_bench_self_launch_propagates_a_failing_rank():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
                                                             'HP3D_RDZV_SECRET', 'HP3D_BENCH_ENTRY')}
     env['HP3D_FAKE_DIE_RANK'] = '1'
+    env['HP3D_BENCH_GRACE_S'] = '3'          # (how long the survivors get before they are stopped: 20 s by default)
     out = subprocess.run([sys.executable, HELPER, '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
                           '--width', '16'], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0

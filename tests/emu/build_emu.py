@@ -18,7 +18,7 @@ def build(force=False):
     for s in SRCS:
         o = os.path.join(HERE, os.path.basename(s).rsplit('.', 1)[0] + '.emu.o')
         objs.append(o)
-        procs.append(subprocess.Popen([CXX, '-x', 'c++', '-std=c++17', '-O2', '-march=native', '-fPIC', '-DHP3D_EMU', '-ffp-contract=off',
+        procs.append(subprocess.Popen([CXX, '-x', 'c++', '-std=c++17', '-O2', '-mavx2', '-mfma', '-mf16c', '-fPIC', '-DHP3D_EMU', '-ffp-contract=off',
                                        '-fno-strict-aliasing', '-w', '-Wno-psabi', '-I', HERE, '-I', CSRC, '-c', s, '-o', o]))
     for p in procs:
         if p.wait() != 0:

@@ -507,7 +507,7 @@ static int wino4_default() {
 }
 bool wino4_auto(int mode, bool posenet, int k, int cin_pad, int cout_pad, int Ho, int Wo, int B, int ks4, int old_nt, int old_ks, int ks2,
                 bool two_streams) {
-    if (mode == -1 && !posenet) return false;              // auto: PoseNet2D only; "all": both trunks
+    if (mode == -1 && !posenet) return false;              // -1 = option "pose": PoseNet2D only; -2 = "auto": both trunks
     if ((long)B * Ho * Wo < 1024) return false;
     const double cus = hp3d_num_cus(), reduce_cost = 0.7;
     const int nsub = k == 7 ? 9 : 1;

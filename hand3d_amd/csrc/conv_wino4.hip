@@ -102,16 +102,31 @@ __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) *
 
 // B^T of F(4x4,3x3) applied to six values in place:
 //   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-__device__ __forceinline__ void w4_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
-    const f32x2 t0 = (4.f * x0 + x4) - 5.f * x2;
-    const f32x2 t5 = (4.f * x1 + x5) - 5.f * x3;
-    const f32x2 s12 = x1 + x2, d12 = x1 - x2, s34 = x3 + x4, d43 = x4 - x3, d31 = x3 - x1, d42 = x4 - x2;
+template <typename T>
+__device__ __forceinline__ void w4_bt_t(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5) {
+    const T t0 = (4.f * x0 + x4) - 5.f * x2;
+    const T t5 = (4.f * x1 + x5) - 5.f * x3;
+    const T s12 = x1 + x2, d12 = x1 - x2, s34 = x3 + x4, d43 = x4 - x3, d31 = x3 - x1, d42 = x4 - x2;
     x0 = t0;
     x1 = s34 - 4.f * s12;
     x2 = d43 + 4.f * d12;
     x3 = d42 + 2.f * d31;
     x4 = d42 - 2.f * d31;
     x5 = t5;
+}
+#ifndef HP3D_W4_SCALAR
+#define HP3D_W4_SCALAR 0           // 1: the input transform on scalar float ops (build with -fno-slp-vectorize): MI355X_MICROARCH.md prices packed f32
+#endif                             //    VALU beside MFMAs higher than two scalar ops; measured here, see profiles/r04_tuning_notes.md
+__device__ __forceinline__ void w4_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
+#if HP3D_W4_SCALAR
+    float a0 = x0[0], a1 = x1[0], a2 = x2[0], a3 = x3[0], a4 = x4[0], a5 = x5[0];
+    float b0 = x0[1], b1 = x1[1], b2 = x2[1], b3 = x3[1], b4 = x4[1], b5 = x5[1];
+    w4_bt_t<float>(a0, a1, a2, a3, a4, a5);
+    w4_bt_t<float>(b0, b1, b2, b3, b4, b5);
+    x0 = f32x2{a0, b0}; x1 = f32x2{a1, b1}; x2 = f32x2{a2, b2}; x3 = f32x2{a3, b3}; x4 = f32x2{a4, b4}; x5 = f32x2{a5, b5};
+#else
+    w4_bt_t<f32x2>(x0, x1, x2, x3, x4, x5);
+#endif
 }
 // A^T of F(4x4,3x3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
@@ -186,12 +201,17 @@ void conv_wino4_kernel(const ConvParams p) {
     auto window_offsets = [&](bool valid, int lb, int lty, int ltx, int sub) {
         const int dy = NSUB == 1 ? 0 : 3 * (sub / 3) - 2, dx = NSUB == 1 ? 0 : 3 * (sub % 3) - 2;
         const int wy0 = 4 * lty - 1 + dy, wx0 = 4 * ltx - 1 + dx;
+#if HP3D_W4_ABL & 1024       // timing ablation: the ADDRESS pattern of a channel-blocked tensor [B][H][C/16][W][16] (same bytes, permuted)
+        const int rowb = (p.in_cs / 16) * p.W * 64;
+        const int wbase = (lb * p.H + wy0) * rowb + wx0 * 64 + lp * 8;
+#else
         const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lp * 8;
+#endif
         const bool tv = valid && lb < p.B;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * p.W * cs4 : OOR;
+        for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * ((HP3D_W4_ABL & 1024) ? (p.in_cs / 16) * p.W * 64 : p.W * cs4) : OOR;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * cs4 : COL_OOR;
+        for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * ((HP3D_W4_ABL & 1024) ? 64 : cs4) : COL_OOR;
 #if HP3D_W4_ABL & 128        // hot windows: every load of the launch comes from one 18 KB region
 #pragma unroll
         for (int r = 0; r < 6; ++r) ro[r] = r * 3072 + lp * 8 + (lt & 7) * 64;
@@ -291,7 +311,7 @@ void conv_wino4_kernel(const ConvParams p) {
     loader_setup(tblock, true, sub0);
     table_write(tblock, 0, kz);
     int wvoff = (cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
-    window_fetch((s0 - sub0 * csteps) * (W4_CK * 4));
+    window_fetch((s0 - sub0 * csteps) * ((HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4));
 #pragma unroll
     for (int t = 0; t < W4_RING; ++t) b_fetch(t, wvoff, soff_of(t, s0));
     transform_commit(0);
@@ -325,7 +345,8 @@ void conv_wino4_kernel(const ConvParams p) {
             const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;
             if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
-            const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * (W4_CK * 4)) : ncs * (W4_CK * 4);
+            const int wstep_b = (HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4;
+            const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * wstep_b) : ncs * wstep_b;
 #pragma unroll
             for (int pl = 0; pl < W4_NP; ++pl) {
                 HP3D_SCHED_BARRIER();
@@ -402,12 +423,14 @@ void conv_wino4_kernel(const ConvParams p) {
                 float z[6][4];                               // A^T M: along the plane rows a
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
-                    w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
+                    if (HP3D_W4_ABL & 512) { z[b][0] = M[b][m][r]; z[b][1] = M[6 + b][m][r]; z[b][2] = M[12 + b][m][r]; z[b][3] = M[18 + b][m][r] + M[24 + b][m][r] + M[30 + b][m][r]; }
+                    else w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
                           z[b][0], z[b][1], z[b][2], z[b][3]);
                 float y[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
+                    if (HP3D_W4_ABL & 512) { y[i][0] = z[0][i]; y[i][1] = z[1][i]; y[i][2] = z[2][i]; y[i][3] = z[3][i] + z[4][i] + z[5][i]; }
+                    else w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
                     if (!POOL) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -427,7 +450,8 @@ void conv_wino4_kernel(const ConvParams p) {
                             float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
                             if (p.act) v = fmaxf(v, HP3D_LEAKY_SLOPE * v);
                             const bool ok = (pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2));
-                            HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
+                            if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(v), "v"(ok ? vo : OOR));
+                            else HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
                         }
                 } else {
                     const int vr = fl & 15, vc = fl >> 4;
@@ -435,7 +459,10 @@ void conv_wino4_kernel(const ConvParams p) {
                     for (int i = 0; i < 4; ++i) {
                         const int vrow = i < vr ? vo : OOR;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, (i * Ws + j) * p.out_cs * 4);
+                        for (int j = 0; j < 4; ++j) {
+                            if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(y[i][j]), "v"(j < vc ? vrow : OOR));
+                            else HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, (i * Ws + j) * p.out_cs * 4);
+                        }
                     }
                 }
             }

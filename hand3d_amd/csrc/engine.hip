@@ -274,6 +274,7 @@ struct hp3d_ctx {
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_lift_fused = -1;   // the lifting stage as one launch (lift_fused.hip): -1 auto (B <= 4), 0 never, 1 always (option "lift_fused")
     unsigned* d_liftbar = nullptr;
+    unsigned* h_lifterr = nullptr;     // mapped host word: lift_fused.hip's grid barrier timed out (results of that launch are invalid)
     long lift_fused_launches = 0;
     bool two_streams_live = false;   // set while a whole-path call runs its two halves on two streams (kernel choice: wino2_auto)
     int use_wino2 = -1;        // conv_wino2.hip (two workgroups per CU): -1 auto (short reductions, under-filled launches), 0 never, 1 wherever eligible (option "wino2")
@@ -885,6 +886,18 @@ int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, floa
     return 0;
 }
 
+// lift_fused.hip's grid barrier gives up after a bounded spin (a workgroup that is not resident would otherwise hang the GPU) and
+// raises this word; every synchronisation point of the executor turns it into an error instead of handing out garbage.
+int check_lift_error(hp3d_ctx* ctx) {
+    if (ctx->h_lifterr && *(volatile unsigned*)ctx->h_lifterr) {
+        *ctx->h_lifterr = 0;
+        HP3D_FAIL(ctx, HP3D_ERR_HIP, "lift_fused: grid barrier timed out (a workgroup was not resident); the outputs of that call are invalid -- "
+                                     "set option lift_fused=0 on a shared GPU");
+    }
+    if (ctx->kid) return check_lift_error(ctx->kid);
+    return 0;
+}
+
 // _inference_pose3d (nets/ColorHandPose3DNetwork.py:221-247)
 // The same two towers as ONE launch (lift_fused.hip): small batches, where 24 dependent launches of ~13 us are the cost
 int run_lift_fused(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int bottleneck, int do_rot) {
@@ -921,6 +934,14 @@ int run_lift_fused(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int
     p.out[0] = ctx->d_can; p.out[1] = ctx->d_u;
     if (!ctx->d_liftbar) CHK(dev_realloc(ctx, &ctx->d_liftbar, 4));
     p.bar = ctx->d_liftbar;
+#ifndef HP3D_EMU
+    if (!ctx->h_lifterr) {
+        HIPCHK(ctx, hipHostMalloc((void**)&ctx->h_lifterr, sizeof(unsigned), hipHostMallocMapped));
+        *ctx->h_lifterr = 0;
+    }
+    CHK(check_lift_error(ctx));            // an earlier launch of this context already failed: do not pile work on garbage
+    HIPCHK(ctx, hipHostGetDevicePointer((void**)&p.err, ctx->h_lifterr, 0));
+#endif
     ProfScope ps(ctx, "PosePrior+ViewpointNet", "lift_fused", 2.0 * B * (45.0e6 / 2 + 157.0e6 / 2 * (do_rot ? 1 : 0) + 2.7e6 / 2), 4.0 * 15.5e6);
     if (lift_fused_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_HIP, "lift_fused launch failed");
     ++ctx->lift_fused_launches;
@@ -1243,7 +1264,7 @@ struct Scratch {
 int finish_op(hp3d_ctx* ctx) {
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return check_lift_error(ctx);
 }
 
 }  // namespace
@@ -1364,6 +1385,9 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     if (ctx->comm) hp3d_comm_destroy(ctx);
     if (ctx->d_seed) hipFree(ctx->d_seed);
     if (ctx->d_liftbar) hipFree(ctx->d_liftbar);
+#ifndef HP3D_EMU
+    if (ctx->h_lifterr) hipHostFree(ctx->h_lifterr);
+#endif
     if (ctx->d_keys) hipFree(ctx->d_keys);
     if (ctx->d_det) hipFree(ctx->d_det);
     if (ctx->d_u8) hipFree(ctx->d_u8);
@@ -1381,7 +1405,7 @@ void* hp3d_stream(hp3d_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int hp3d_sync(hp3d_ctx* ctx) {
     if (!ctx) return HP3D_ERR_ARG;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    return 0;
+    return check_lift_error(ctx);
 }
 
 // ---- device / pinned-host memory for callers that hold their batches in HBM (bench.py, dist.py): the C ABI needs no

@@ -21,6 +21,8 @@ struct LiftFusedParams {
     float* fcp[2][2];         // per tower: partial sums of fc layer 0 / 1, [K slices][B][Cout]
     float* out[2];            // [B,63] canonical coordinates; [B,3] rotation vector
     unsigned* bar;            // grid-barrier counter (zeroed by the launcher)
+    unsigned* err;            // error word in mapped host memory: set to 1 by a workgroup whose barrier wait ran out (the
+                              // executor checks it at every synchronisation point and fails the call: hp3d_sync / finish_op)
     int B, towers;            // towers: bit 0 PosePrior, bit 1 ViewpointNet
     int phase_lo, phase_hi;   // set by the launcher
 };

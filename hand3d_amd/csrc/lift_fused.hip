@@ -38,7 +38,7 @@ constexpr int LF_SMEM_BYTES = (LF_PATCH_FLOATS + LF_RED_FLOATS) * 4;
 #ifndef HP3D_EMU
 // grid barrier: one monotonic counter; every workgroup drains its stores, ONE lane releases at agent scope, arrives, polls relaxed
 // (agent-scope loads) until everybody of this round is there, acquires at agent scope; then the workgroup goes on with plain loads.
-__device__ __forceinline__ void lf_grid_barrier(unsigned* counter, unsigned target) {
+__device__ __forceinline__ void lf_grid_barrier(unsigned* counter, unsigned target, unsigned* err) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // every wave: its stores of this phase have left
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -48,7 +48,10 @@ __device__ __forceinline__ void lf_grid_barrier(unsigned* counter, unsigned targ
         unsigned spins = 0;
         while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 26)) break;             // a lost workgroup must not hang the GPU: results would be wrong, loudly
+            if (++spins > (1u << 24)) {                  // a workgroup that never arrives must not hang the GPU: the outputs of this
+                __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // launch are garbage, and the host is told so
+                break;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -271,7 +274,7 @@ void lift_fused_kernel(const LiftFusedParams p) {
             }
         }
 #ifndef HP3D_EMU
-        if (phase < p.phase_hi && !(p.towers & 256)) lf_grid_barrier(p.bar, ++bar_round * (unsigned)nwg);
+        if (phase < p.phase_hi && !(p.towers & 256)) lf_grid_barrier(p.bar, ++bar_round * (unsigned)nwg, p.err);
 #endif
     }
 }
@@ -291,14 +294,30 @@ int lift_fused_launch(const LiftFusedParams& pin, hipStream_t s) {
     }
 #else
     if (hipMemsetAsync(p.bar, 0, sizeof(unsigned), s) != hipSuccess) return -1;
+    // The hand-rolled grid barrier needs every workgroup RESIDENT at once.  One workgroup per two CUs by design; clamped to what the
+    // occupancy query says fits (16 waves, 42 KB of LDS: one or two per CU) minus the margin MI355X_MICROARCH.md asks for near the
+    // API's edge.  A GPU shared with other work can still delay a workgroup: the barrier's bounded spin then raises p.err.
+    static int resident[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!resident[dev]) {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)lift_fused_kernel, LF_THREADS, LF_SMEM_BYTES) != hipSuccess || per_cu < 1) per_cu = 1;
+        resident[dev] = per_cu * hp3d_num_cus();
+    }
     int nwg = hp3d_num_cus() / 2 > 0 ? hp3d_num_cus() / 2 : 1;
-    if (const char* e = getenv("HP3D_LIFT_WGS")) { const int v = atoi(e); if (v > 0 && v <= 4 * hp3d_num_cus()) nwg = v; }     // tuning knob
     p.phase_lo = 0; p.phase_hi = 8;
+#ifdef HP3D_TUNING      // tuning builds only: a stray environment variable must not change (or corrupt) a deployment's results
+    if (const char* e = getenv("HP3D_LIFT_WGS")) { const int v = atoi(e); if (v > 0) nwg = v; }
     if (const char* e = getenv("HP3D_LIFT_ABL")) {          // timing ablations (wrong results): 1 = no grid barriers, 2 = barriers only
         if (atoi(e) == 1) p.towers |= 256;
         if (atoi(e) == 2) p.B = 0;
         if (atoi(e) >= 10) p.phase_hi = atoi(e) - 10;       // 10 + n: phases 0..n only
     }
+#endif
+    const int cap = resident[dev] > hp3d_num_cus() ? resident[dev] - hp3d_num_cus() / 8 : resident[dev] * 7 / 8;
+    if (nwg > cap) nwg = cap > 0 ? cap : 1;
     HP3D_LAUNCH(lift_fused_kernel, dim3(nwg), dim3(LF_THREADS), LF_SMEM_BYTES, s, p);
 #endif
     return 0;

@@ -10,8 +10,8 @@ MASTER_ADDR / MASTER_PORT (torch.distributed.run does; so does a shell loop), an
 agree on before RCCL exists -- the 128-byte communicator id -- travels over a plain TCP socket (`Rendezvous`), which
 also carries the host-side scalars of the benchmark protocol (barrier, max of the per-rank wall times).
 
-The torch.distributed helpers at the bottom (`broadcast_blob`, `gather_keypoints`) remain for callers that already
-live inside a torch process group (and for the gloo CPU test); nothing in the product path imports torch.
+Nothing in this package imports torch.  Callers that already live inside a torch process group find torch.distributed
+variants of the two exchanges in `examples/torch_dist_helpers.py` (outside the product package; two-rank gloo test).
 """
 import hashlib
 import hmac
@@ -78,7 +78,12 @@ def _enc(obj, out):
         raise TypeError("rendezvous: cannot send %r" % type(obj))
 
 
-def _dec(buf, pos):
+_MAX_DEPTH = 16          # nesting of lists / maps a message may have (a hostile peer must not be able to exhaust the stack)
+
+
+def _dec(buf, pos, depth=0):
+    if depth > _MAX_DEPTH:
+        raise ValueError("rendezvous: message nested deeper than %d" % _MAX_DEPTH)
     tag = buf[pos:pos + 1]
     pos += 1
     if tag == b'N':
@@ -118,13 +123,13 @@ def _dec(buf, pos):
         if tag == b'L':
             out = []
             for _ in range(n):
-                x, pos = _dec(buf, pos)
+                x, pos = _dec(buf, pos, depth + 1)
                 out.append(x)
             return out, pos
         d = {}
         for _ in range(n):
-            k, pos = _dec(buf, pos)
-            v, pos = _dec(buf, pos)
+            k, pos = _dec(buf, pos, depth + 1)
+            v, pos = _dec(buf, pos, depth + 1)
             if not isinstance(k, str):
                 raise ValueError("rendezvous: bad dict key")
             d[k] = v
@@ -227,7 +232,7 @@ class Rendezvous(object):
                 except socket.timeout:
                     continue
                 try:
-                    c.settimeout(10.0)
+                    c.settimeout(2.0)            # the handshake is two short messages on a local link: a silent stranger costs 2 s, not 10
                     nonce = os.urandom(16)
                     c.sendall(_MAGIC + nonce)
                     hello = _recv_exact(c, len(_MAGIC) + 4 + 32)          # fixed size; nothing is parsed before the MAC holds
@@ -385,60 +390,3 @@ class ShardedPipeline(object):
             self.engine.comm_destroy()
             self.comm_ready = False
         self.rdzv.close()
-
-
-# ------------------------------------------------------------------------------------------- torch.distributed variants
-def broadcast_blob(blob_tensor, src=0, group=None):
-    """In-place broadcast of the packed weight blob (a flat torch tensor on the rank's device) inside an existing
-    torch process group."""
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.broadcast(blob_tensor, src=src, group=group)
-    return blob_tensor
-
-
-def gather_keypoints(local_kp, n_total=None, group=None):
-    """all_gather of per-rank keypoints [b_r,21,3] (torch tensors) -> [sum b_r,21,3] in rank order.  Ragged shards are
-    padded to the largest shard."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return local_kp
-    world = dist.get_world_size(group)
-    if n_total is None:
-        sizes_t = [torch.zeros(1, dtype=torch.int64, device=local_kp.device) for _ in range(world)]
-        dist.all_gather(sizes_t, torch.tensor([local_kp.shape[0]], dtype=torch.int64, device=local_kp.device), group=group)
-        sizes = [int(s.item()) for s in sizes_t]
-    else:
-        sizes = shard_sizes(n_total, world)
-    mx = max(sizes)
-    pad = local_kp
-    if local_kp.shape[0] < mx:
-        pad = torch.cat([local_kp, local_kp.new_zeros((mx - local_kp.shape[0],) + tuple(local_kp.shape[1:]))], 0)
-    outs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(outs, pad.contiguous(), group=group)
-    return torch.cat([o[:s] for o, s in zip(outs, sizes)], 0)
-
-
-def sync_weights_torch(engine, rank, world, weights=None, device=None, dtype=0, group=None):
-    """The weight exchange through torch.distributed (backend nccl = RCCL) for callers inside a torch process group:
-    hp3d_weights_blob_export -> dist.broadcast -> hp3d_weights_blob_import, with rank 0's real nets mask."""
-    import torch
-    import torch.distributed as dist
-    if rank == 0:
-        engine.load_weight_dict(weights)
-        engine.finalize_weights(dtype)
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    mask = torch.tensor([engine.nets_mask() if rank == 0 else 0], dtype=torch.int64, device=device)
-    dist.broadcast(mask, src=0, group=group)
-    n = (engine.blob_bytes() + 3) // 4
-    blob = torch.empty(n, dtype=torch.float32, device=device)
-    if rank == 0:
-        engine.blob_export(blob.data_ptr())
-    broadcast_blob(blob, 0, group)
-    if device is not None and getattr(device, 'type', 'cpu') == 'cuda':
-        torch.cuda.synchronize(device)
-    if rank != 0 or world == 1:
-        engine.blob_import(blob.data_ptr(), int(mask.item()))
-    del blob

@@ -21,21 +21,50 @@ import numpy as np
 from .._lib import Engine
 
 
+def read_weight_file(file_name):
+    """One weight file -> dict[tf variable name -> ndarray].  `.pickle` is the reference's format (a pickled dict, :50-53);
+    `.npz` holds the same keys and arrays (BASELINE.json's wording "loads the existing .npz weights"):
+    written by `export_npz` / `pickle_to_npz` below, read without unpickling anything."""
+    assert os.path.exists(file_name), "File not found."
+    if file_name.endswith('.npz'):
+        with np.load(file_name, allow_pickle=False) as z:
+            return {k: z[k] for k in z.files}
+    with open(file_name, 'rb') as fi:
+        return pickle.load(fi, encoding='latin1')
+
+
 def load_weight_files(engine, weight_files, exclude_var_list=None, verbose=True):
     """The loading loop of ColorHandPose3DNetwork.init (:50-59) / PosePriorNetwork.init (:47-57):
-    unpickle dict[str -> ndarray], drop keys containing any exclude substring, assign by name."""
+    read dict[str -> ndarray] (pickle or .npz), drop keys containing any exclude substring, assign by name.
+    Returns the merged dict of what was assigned (later files win, like repeated assign ops)."""
     if exclude_var_list is None:
         exclude_var_list = list()
+    loaded = dict()
     for file_name in weight_files:
-        assert os.path.exists(file_name), "File not found."
-        with open(file_name, 'rb') as fi:
-            weight_dict = pickle.load(fi, encoding='latin1')
-            weight_dict = {k: v for k, v in weight_dict.items() if not any([x in k for x in exclude_var_list])}
-            if len(weight_dict) > 0:
-                engine.load_weight_dict(weight_dict)
-                if verbose:
-                    print('Loaded %d variables from %s' % (len(weight_dict), file_name))
+        weight_dict = read_weight_file(file_name)
+        weight_dict = {k: v for k, v in weight_dict.items() if not any([x in k for x in exclude_var_list])}
+        if len(weight_dict) > 0:
+            engine.load_weight_dict(weight_dict)
+            loaded.update(weight_dict)
+            if verbose:
+                print('Loaded %d variables from %s' % (len(weight_dict), file_name))
     engine.finalize_weights()
+    return loaded
+
+
+def save_npz(weight_dict, npz_path):
+    """dict[tf variable name -> ndarray] -> one uncompressed .npz with the same keys (float32, C order)."""
+    np.savez(npz_path, **{k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weight_dict.items()})
+
+
+def pickle_to_npz(weight_files, npz_path, exclude_var_list=None):
+    """Converts the reference's weight pickles (one or several, merged in order) into one .npz that `init` accepts."""
+    merged = dict()
+    for file_name in weight_files:
+        d = read_weight_file(file_name)
+        merged.update({k: v for k, v in d.items() if not any([x in k for x in (exclude_var_list or [])])})
+    save_npz(merged, npz_path)
+    return sorted(merged)
 
 
 class ColorHandPose3DNetwork(object):
@@ -45,19 +74,25 @@ class ColorHandPose3DNetwork(object):
         self.crop_size = 256
         self.num_kp = 21
         self.engine = engine if engine is not None else Engine(device)
+        self.weight_dict = dict()
 
     def init(self, session=None, weight_files=None, exclude_var_list=None):
-        """ Initializes weights from pickled python dictionaries (reference :34-59).
+        """ Initializes weights from pickled python dictionaries (reference :34-59) or from `.npz` files with the same keys.
             `session` is accepted for call compatibility and ignored. """
         if weight_files is None:
             weight_files = ['./weights/handsegnet-rhd.pickle', './weights/posenet3d-rhd-stb-slr-finetuned.pickle']
-        load_weight_files(self.engine, weight_files, exclude_var_list)
+        self.weight_dict.update(load_weight_files(self.engine, weight_files, exclude_var_list))
 
     def init_from_dict(self, weight_dict, dtype=0):
         """Convenience for synthetic weights: the merged content of the weight files.
         dtype='f16' selects the half-precision trunks (BASELINE config 5)."""
         self.engine.load_weight_dict(weight_dict)
         self.engine.finalize_weights(dtype)
+        self.weight_dict.update(weight_dict)
+
+    def export_npz(self, npz_path):
+        """ Writes every variable assigned so far into one `.npz` (keys = TF variable names) that `init` reads back. """
+        save_npz(self.weight_dict, npz_path)
 
     @staticmethod
     def _check_eval(evaluation):

@@ -6,7 +6,7 @@ All five variants run on the engine: 'direct', 'bottleneck', 'proposed', and 'lo
 from __future__ import print_function, unicode_literals
 
 from .._lib import Engine
-from .ColorHandPose3DNetwork import load_weight_files
+from .ColorHandPose3DNetwork import load_weight_files, save_npz
 
 
 class PosePriorNetwork(object):
@@ -16,15 +16,20 @@ class PosePriorNetwork(object):
         self.num_kp = 21
         self.variant = variant
         self.engine = engine if engine is not None else Engine(device)
+        self.weight_dict = dict()
 
     def init(self, session=None, weight_files=None, exclude_var_list=None):
-        """ reference :36-57 -- weight_files is required there (no default). """
+        """ reference :36-57 -- weight_files is required there (no default); `.pickle` or `.npz`. """
         assert weight_files is not None, "weight_files is required"
-        load_weight_files(self.engine, weight_files, exclude_var_list)
+        self.weight_dict.update(load_weight_files(self.engine, weight_files, exclude_var_list))
 
     def init_from_dict(self, weight_dict):
         self.engine.load_weight_dict(weight_dict)
         self.engine.finalize_weights()
+        self.weight_dict.update(weight_dict)
+
+    def export_npz(self, npz_path):
+        save_npz(self.weight_dict, npz_path)
 
     def inference(self, scoremap, hand_side, evaluation):
         """ Infere 3D coordinates from 2D scoremaps (reference :59-95).

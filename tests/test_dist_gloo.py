@@ -22,7 +22,8 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from hand3d_amd.dist import broadcast_blob, gather_keypoints, shard_range
+    from examples.torch_dist_helpers import broadcast_blob, gather_keypoints
+    from hand3d_amd.dist import shard_range
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -63,6 +64,7 @@ def test_two_rank_gloo_broadcast_and_gather():
 
 def test_single_process_degrades_to_identity():
     import torch
-    from hand3d_amd.dist import gather_keypoints
+    sys.path.insert(0, ROOT)
+    from examples.torch_dist_helpers import gather_keypoints
     x = torch.randn(3, 21, 3)
     assert gather_keypoints(x) is x

@@ -130,3 +130,23 @@ def test_native_rccl_two_ranks_on_one_gpu(gpu_engine, synth_weights):
         exp = gpu_engine.infer_full(synth.make_batch(40 + r, 1, 240, 320), synth.hand_sides(1), outputs=('coord3d',))['coord3d']
         assert np.abs(res[r][2] - exp).max() < 1e-6
         assert np.array_equal(res[0][3][r], res[r][2][0]) and np.array_equal(res[1][3][r], res[r][2][0])
+
+
+def test_wire_codec_round_trip_and_depth_cap():
+    """The rendezvous codec carries None / bool / int / float / str / bytes / ndarray / list / map and nothing else, and refuses
+    messages nested deeper than its cap (a peer must not be able to run the receiver out of stack)."""
+    import struct
+    from hand3d_amd import dist
+    msg = {'a': [1, 2.5, None, True, 'x', b'\x00\x01', np.arange(6, dtype=np.float32).reshape(2, 3)], 'b': {'c': [[], {}]}}
+    parts = []
+    dist._enc(msg, parts)
+    buf = b''.join(parts)
+    back, pos = dist._dec(buf, 0)
+    assert pos == len(buf) and back['a'][:6] == msg['a'][:6] and np.array_equal(back['a'][6], msg['a'][6]) and back['b'] == msg['b']
+    deep = b''.join(b'L' + struct.pack('<Q', 1) for _ in range(dist._MAX_DEPTH + 2)) + b'N'
+    with pytest.raises(ValueError, match='nested deeper'):
+        dist._dec(deep, 0)
+    ok = b''.join(b'L' + struct.pack('<Q', 1) for _ in range(dist._MAX_DEPTH)) + b'N'
+    assert dist._dec(ok, 0)[1] == len(ok)
+    with pytest.raises(TypeError):
+        dist._enc(object(), [])

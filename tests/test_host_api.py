@@ -54,6 +54,47 @@ def test_weight_files_loading_and_exclusion(tmp_path, emu_engine, synth_weights)
     e2.close()
 
 
+def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
+    """BASELINE.json's north star says ".npz weights"; the reference's loader is pickle (nets/ColorHandPose3DNetwork.py:45-59).
+    Both are accepted: pickle -> export_npz / pickle_to_npz -> init(.npz) gives the same engine state and the same outputs."""
+    from hand3d_amd import Engine
+    from hand3d_amd.nets.ColorHandPose3DNetwork import pickle_to_npz, read_weight_file
+    paths = synth.write_weight_files(str(tmp_path), synth_weights)
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init(None, weight_files=paths)
+    npz = str(tmp_path / 'all.npz')
+    net.export_npz(npz)
+    back = read_weight_file(npz)
+    assert sorted(back) == sorted(synth_weights)
+    for k, v in synth_weights.items():
+        assert back[k].dtype == np.float32 and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    # the converter on the files gives the same archive content; exclusion applies to .npz files like to pickles
+    npz2 = str(tmp_path / 'conv.npz')
+    keys = pickle_to_npz(paths, npz2)
+    assert keys == sorted(synth_weights) and all(np.array_equal(read_weight_file(npz2)[k], back[k]) for k in keys)
+    e2 = Engine(0, path=emu_engine.lib._name)
+    net2 = ColorHandPose3DNetwork(engine=e2)
+    net2.init(None, weight_files=[npz])
+    assert e2.nets_mask() & 15 == 15
+    rng = np.random.RandomState(5)
+    img = (rng.rand(1, 16, 24, 3).astype(np.float32) - 0.5)
+    hs = np.array([[1., 0.]], np.float32)
+    a = net.inference(img, hs, True)
+    b = net2.inference(img, hs, True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    e3 = Engine(0, path=emu_engine.lib._name)
+    net3 = ColorHandPose3DNetwork(engine=e3)
+    net3.init(None, weight_files=[npz], exclude_var_list=['PosePrior', 'ViewpointNet'])
+    assert e3.nets_mask() & 15 == 3
+    pp = PosePriorNetwork('direct', engine=Engine(0, path=emu_engine.lib._name))
+    pp.init(None, weight_files=[npz], exclude_var_list=['HandSegNet', 'PoseNet2D', 'ViewpointNet'])
+    assert pp.engine.nets_mask() & 15 == 4
+    with pytest.raises(AssertionError, match="File not found."):
+        net3.init(None, weight_files=[str(tmp_path / 'missing.npz')])
+    e2.close(); e3.close(); pp.engine.close()
+
+
 def test_error_behaviour(emu_engine, synth_weights):
     net = ColorHandPose3DNetwork(engine=emu_engine)
     net.init_from_dict(synth_weights)

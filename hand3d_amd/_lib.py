@@ -23,6 +23,7 @@ _ctx = C.c_void_p
 
 _SIGNATURES = {
     'hp3d_abi_version': (C.c_int, []),
+    'hp3d_device_count': (C.c_int, [C.POINTER(C.c_int)]),
     'hp3d_create': (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     'hp3d_destroy': (C.c_int, [_ctx]),
     'hp3d_last_error': (C.c_char_p, [_ctx]),
@@ -116,6 +117,13 @@ def load(path=None):
     _loaded[path] = lib
     _lib, _lib_path = lib, path
     return lib
+
+
+def device_count(path=None):
+    """HIP devices visible to this process (hp3d_device_count); 0 when the runtime reports an error (no GPU, no driver)."""
+    n = C.c_int(0)
+    rc = load(path).hp3d_device_count(C.byref(n))
+    return int(n.value) if rc == 0 else 0
 
 
 def _ptr(a):

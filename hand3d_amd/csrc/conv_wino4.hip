@@ -33,20 +33,10 @@
 #define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
 #endif
 
-#ifndef HP3D_W4_SYNC
-#define HP3D_W4_SYNC 0             // 0: one __syncthreads per step; 1: LDS-counter hand-off between the four waves (measured: -0.5 %, see below)
-#endif
 #ifndef HP3D_W4_ORDER
 #define HP3D_W4_ORDER 1            // 1: XCD-affine item order (conv3_2 -6 %), 0: cout-block-major like conv_wino.hip
 #endif
-#ifndef HP3D_W4_NT
-#define HP3D_W4_NT 0
-#endif
-#if HP3D_W4_NT
-#define W4_WLOAD HP3D_BUFFER_LOAD8_NT
-#else
 #define W4_WLOAD HP3D_BUFFER_LOAD8
-#endif
 
 namespace {
 
@@ -56,7 +46,7 @@ constexpr int W4_COUTS = 64;                       // output channels per item (
 constexpr int W4_NP = 36;                          // planes
 constexpr int W4_PLANE_FLOATS = W4_TILES * W4_CK;  // one plane of one V buffer: 2 KB
 constexpr int W4_VBUF_FLOATS = W4_NP * W4_PLANE_FLOATS;
-constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4 + 16;     // 2 V buffers + two tile tables + two hand-off counters = 147984 B
+constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4;     // 2 V buffers + two tile tables = 147968 B
 #ifndef HP3D_W4_RING
 #define HP3D_W4_RING 9
 #endif
@@ -80,22 +70,6 @@ constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: th
 #define HP3D_W4_TAT 29
 #endif
 constexpr int W4_TRANSFORM_AT = HP3D_W4_TAT;       // the plane under which the next step's windows are transformed
-
-// issue order of the 36 window elements.  Neighbouring tiles' windows overlap by two rows / columns, so (r >= 4, c) is the pixel another
-// lane loads as (r - 4, c) and (r, c >= 4) the one loaded as (r, c - 4): in row-major order the two requests for a line follow each
-// other within two planes, i.e. the second one hits a line whose fill is still pending.  HP3D_W4_ISSUE = 1 walks the window in 2x2
-// blocks ordered so that every such pair lies at least six planes apart.
-#ifndef HP3D_W4_ISSUE
-#define HP3D_W4_ISSUE 0
-#endif
-__host__ __device__ constexpr int w4_issue_order(int k) {
-#if HP3D_W4_ISSUE
-    constexpr int blk[9][2] = {{0, 0}, {0, 1}, {1, 0}, {1, 1}, {0, 2}, {2, 0}, {2, 1}, {1, 2}, {2, 2}};
-    return (2 * blk[k / 4][0] + ((k >> 1) & 1)) * 6 + 2 * blk[k / 4][1] + (k & 1);
-#else
-    return k;
-#endif
-}
 
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
 __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }
@@ -143,13 +117,6 @@ void conv_wino4_kernel(const ConvParams p) {
     static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
     HP3D_DYN_SMEM(V);
     int* tinfo = (int*)(V + 2 * W4_VBUF_FLOATS);       // [parity][0..31] output offset of tile t (-1: none), [32..63] edge flags
-    // hand-off counters (HP3D_W4_SYNC): sync[0] += 1 per wave that has WRITTEN its share of the next step's V, sync[1] += 1 per wave
-    // that has finished READING the current step's V.  A step ends with "all four wrote" instead of a barrier -- the writes happen
-    // under plane 29, six planes before they are needed, so a wave that runs a little late no longer holds the other three -- and
-    // "all four read step g - 1" guards the buffer before step g's transform overwrites it.  Built because removing the barrier altogether
-    // (a timing ablation with wrong results) gained 10 %; measured: 2100 vs 2113 images/s for the barrier -- what the ablation gained was
-    // the waves drifting a whole step apart, which no correct hand-off allows.  Kept as a build knob, off.
-    int* sync = tinfo + 2 * 2 * W4_TILES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
     const int ln = lane & 15, lq = lane >> 4;          // MFMA column (cout / tile in block) and k slot
@@ -272,10 +239,7 @@ void conv_wino4_kernel(const ConvParams p) {
 
     f32x4 M[W4_NP][2];     // [plane][tile half]: rows = tiles 16 m + 4 (lane >> 4) + r, column = cout (lane & 15)
     f32x4 bq[W4_RING];
-#ifndef HP3D_W4_BAUX
-#define HP3D_W4_BAUX 0           // cache policy of the weight-fragment loads (experiments: 16 = sc1, 2 = nt)
-#endif
-    auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_W4_BAUX ? HP3D_BUFFER_LOAD16_AUX(wrsrc, voff, soff, HP3D_W4_BAUX) : HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
+    auto b_fetch = [&](int slot, int voff, int soff) { bq[slot] = HP3D_BUFFER_LOAD16(wrsrc, voff, soff); };
     const int va_lane = (ln * W4_CK + ((lq ^ w4_swz(ln)) * 4)) * 4;
     int ab0 = 0, ab1 = 0;
     f32x4 af[W4_ADEPTH][2];
@@ -315,10 +279,8 @@ void conv_wino4_kernel(const ConvParams p) {
 #pragma unroll
     for (int t = 0; t < W4_RING; ++t) b_fetch(t, wvoff, soff_of(t, s0));
     transform_commit(0);
-    if (HP3D_W4_SYNC && tid < 2) sync[tid] = 0;
     __syncthreads();
     int cur = 0;
-    int gstep = 0;                                     // steps this workgroup has completed (all items)
 
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0;
@@ -371,24 +333,16 @@ void conv_wino4_kernel(const ConvParams p) {
                 if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
 #pragma unroll
                     for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
-                        const int e = w4_issue_order(pl * W4_WPP + j);
+                        const int e = pl * W4_WPP + j;
                         d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
                     }
                 }
                 if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) {
-                    if (HP3D_W4_SYNC) HP3D_LDS_WAIT_GE(sync + 1, 4 * gstep);       // V[cur ^ 1] was read in step gstep - 1: all four done?
                     transform_commit(cur ^ 1);
-                    if (HP3D_W4_SYNC) HP3D_LDS_SIGNAL(sync + 0, lane);
                 }
             }
             HP3D_SCHED_BARRIER();
-            if (HP3D_W4_SYNC) {
-                HP3D_LDS_SIGNAL(sync + 1, lane);                                // this wave's reads of V[cur] are issued (LDS is in order)
-                HP3D_LDS_WAIT_GE(sync + 0, 4 * (gstep + 1));                    // V[cur ^ 1] complete?
-                ++gstep;
-            } else if (!(HP3D_W4_ABL & 4)) {
-                __syncthreads();             // V[cur^1] complete, V[cur] free
-            }
+            if (!(HP3D_W4_ABL & 4)) __syncthreads();             // V[cur^1] complete, V[cur] free
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };

@@ -1326,6 +1326,20 @@ extern "C" {
 
 int hp3d_abi_version(void) { return 1; }
 
+int hp3d_device_count(int* count) {
+    if (!count) return HP3D_ERR_ARG;
+    *count = 0;
+#ifdef HP3D_EMU
+    *count = 1;             // the CPU interpreter plays one device
+    return 0;
+#else
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return HP3D_ERR_HIP; }
+    *count = n;
+    return 0;
+#endif
+}
+
 int hp3d_create(int device, hp3d_ctx** out) {
     if (!out) return HP3D_ERR_ARG;
     *out = nullptr;

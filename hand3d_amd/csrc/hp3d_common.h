@@ -112,23 +112,6 @@ static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
 #define HP3D_ACQUIRE_AGENT() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #define HP3D_TICKET_AGENT(ptr) __hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define HP3D_STORE_RELAXED_AGENT(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-// Hand-off between the waves of ONE workgroup through a counter in LDS, instead of s_barrier: a producer wave adds 1 after its LDS
-// writes (or reads) -- the LDS unit executes a wave's instructions in issue order, so whoever sees the count sees them done -- and a
-// consumer polls until the count it needs is there.  Relaxed atomics + compiler barriers only: a C++ release / acquire at workgroup
-// scope would also drain vmcnt, i.e. the weight ring.
-#define HP3D_LDS_SIGNAL(ptr, lane)                                                                         \
-    do {                                                                                                   \
-        asm volatile("" ::: "memory");                                                                     \
-        if ((lane) == 0) (void)__hip_atomic_fetch_add((ptr), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); \
-        asm volatile("" ::: "memory");                                                                     \
-    } while (0)
-#define HP3D_LDS_WAIT_GE(ptr, target)                                                                      \
-    do {                                                                                                   \
-        asm volatile("" ::: "memory");                                                                     \
-        while ((int)(__builtin_amdgcn_readfirstlane(__hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) - (int)(target)) < 0) \
-            __builtin_amdgcn_s_sleep(1);                                                                   \
-        asm volatile("" ::: "memory");                                                                     \
-    } while (0)
 #define HP3D_KERNEL(nthr) __global__ __launch_bounds__(nthr)
 #define HP3D_KERNEL2(nthr, waves_per_simd) __global__ __launch_bounds__(nthr, waves_per_simd)
 #define HP3D_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
@@ -175,12 +158,6 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 8 B per lane (same addressing / range check)
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) \
     __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 0))
-// 16 B per lane with an explicit cache-policy immediate (bit 0 sc0, bit 1 nt, bit 4 sc1): tuning experiments only
-#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) \
-    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), (aux)))
-// 8 B per lane, non-temporal (nt): a streaming read that should not displace other lines of the L2
-#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) \
-    __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 2))
 // 16 B per lane at agent scope (sc1): the consuming side of an in-launch hand-off whose payload was stored write-through
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 16))
@@ -208,9 +185,7 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
-#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
-#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))

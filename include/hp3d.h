@@ -47,6 +47,10 @@ enum { HP3D_VARIANT_DIRECT = 0, HP3D_VARIANT_BOTTLENECK = 1, HP3D_VARIANT_PROPOS
 enum { HP3D_ACT_NONE = 0, HP3D_ACT_LEAKY = 1 };
 
 int hp3d_abi_version(void);
+/* HIP devices visible to this process (hipGetDeviceCount); needs no context.  No reference counterpart (one tf.Session on whatever
+ * device TensorFlow picks, run.py:44-50): a launcher uses it to refuse `--gpus N` on a box with fewer devices BEFORE any rank
+ * starts, instead of leaving N - n ranks to fail one by one inside a rendezvous.  Returns 0 or HP3D_ERR_HIP (then *count = 0). */
+int hp3d_device_count(int* count);
 
 /* ---- context ----------------------------------------------------------------------------
  * replaces: tf.Session(config=...) + graph construction (run.py:44-50).                     */

@@ -75,7 +75,6 @@ static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
 }
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
-#define HP3D_BUFFER_LOAD16_AUX(rsrc, voff, soff, aux) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     float v = 0.f;
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy(&v, r.base + voff + soff, 4);
@@ -88,7 +87,6 @@ static inline f32x2 hp3d_emu_buffer_load8(hp3d_rsrc_t r, unsigned voff, unsigned
     return v;
 }
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) hp3d_emu_buffer_load8((rsrc), (unsigned)(voff), (unsigned)(soff))
-#define HP3D_BUFFER_LOAD8_NT(rsrc, voff, soff) hp3d_emu_buffer_load8((rsrc), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }
@@ -122,8 +120,6 @@ void hp3d_emu_syncthreads();
 void hp3d_emu_yield();
 // LDS-counter hand-off inside a workgroup (conv_wino4.hip): one lane of a wave adds 1; a waiter lets the other fibers run until the count is reached
 void hp3d_emu_wave_sync();
-#define HP3D_LDS_SIGNAL(ptr, lane) do { hp3d_emu_wave_sync(); if ((lane) == 0) *(ptr) += 1; } while (0)       /* (a wave's lanes are fibers here) */
-#define HP3D_LDS_WAIT_GE(ptr, target) do { while ((int)(*(volatile int*)(ptr) - (int)(target)) < 0) hp3d_emu_yield(); } while (0)
 #define __syncthreads hp3d_emu_syncthreads
 f32x16 hp3d_emu_mfma_32x32x2(float a, float b, f32x16 c);
 #define HP3D_MFMA_32x32x2(a, b, c) hp3d_emu_mfma_32x32x2((a), (b), (c))

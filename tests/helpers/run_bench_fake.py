@@ -108,6 +108,7 @@ class FakeEngine(object):
 os.environ['HP3D_BENCH_ENTRY'] = os.path.abspath(__file__)      # bench.py's self-launch starts THIS script per rank
 hand3d_amd.Engine = FakeEngine
 _lib.Engine = FakeEngine
+_lib.device_count = lambda path=None: int(os.environ.get('HP3D_FAKE_DEVICES', '64'))     # (the stand-in box has as many devices as a test says)
 sys.argv = ['bench.py'] + sys.argv[1:]
 runpy.run_path(os.path.join(ROOT, 'bench.py'), run_name='__main__')
 sys.stderr.write('FAKELOG rank %s: %s\n' % (os.environ.get('RANK', '-'), ' | '.join(FakeEngine.log)))

@@ -115,3 +115,21 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     out = subprocess.run([sys.executable, HELPER, '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
                           '--width', '16'], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and 'WORLD_SIZE' in out.stderr and out.stdout.strip() == ''
+
+
+@pytest.mark.parametrize('launched', [False, True])
+def test_bench_refuses_more_gpus_than_devices(launched):
+    """`--gpus 8` on a box that shows 2 devices: one line on stderr and exit code 3 -- before any rank is started (plain call) or
+    before the rank joins a rendezvous (under a launcher); nothing hangs, nothing is printed on stdout."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'HP3D_RDZV_SECRET', 'HP3D_BENCH_ENTRY')}
+    env['HP3D_FAKE_DEVICES'] = '2'
+    if launched:
+        env.update(RANK='5', WORLD_SIZE='8', LOCAL_RANK='5', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, HELPER, '--gpus', '8', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
+                          '--width', '16'], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 3 and out.stdout.strip() == ''
+    assert 'only 2 HIP device(s)' in out.stderr and 'FAKELOG rank' not in out.stderr.replace('FAKELOG rank %s: \n' % env.get('RANK', '-'), '')
+    assert time.time() - t0 < 60

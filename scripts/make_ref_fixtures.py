@@ -28,9 +28,10 @@ from hand3d_amd import synth  # noqa: E402
 OUT = os.path.join(ROOT, 'tests', 'golden')
 C1_SEEDS = (0, 1, 2, 3, 4)               # BASELINE config 1: 5 images, 240 x 320, B = 1
 C3_SEED0 = 200
+C4_SEED0 = 300                           # BASELINE config 4's per-GPU shard in small: one batch of 8, 240 x 320
 
 
-def export_inputs(d):
+def export_inputs(d, with_c4=True):
     """Everything scripts/make_tf_fixtures.py reads: plain .npy / .npz / protocol-2 pickles (old NumPy / Python 2 safe)."""
     os.makedirs(d, exist_ok=True)
     w = synth.make_weights(seed=42)
@@ -44,6 +45,10 @@ def export_inputs(d):
             np.array([[0.0, 1.0] if s % 2 else [1.0, 0.0] for s in C1_SEEDS], np.float32))
     np.save(os.path.join(d, 'c3_seed0.npy'), np.array(C3_SEED0))
     np.save(os.path.join(d, 'c3_images.npy'), synth.make_batch(C3_SEED0, 2, 320, 320))
+    if with_c4:
+        np.save(os.path.join(d, 'c4_seed0.npy'), np.array(C4_SEED0))
+        np.save(os.path.join(d, 'c4_images.npy'), synth.make_batch(C4_SEED0, 8, 240, 320))
+        np.save(os.path.join(d, 'c4_hand_sides.npy'), synth.hand_sides(8))
     np.savez(os.path.join(d, 'mask_cases.npz'), **{c: synth.blob_scoremap(c) for c in synth.MASK_CASES})
     np.save(os.path.join(d, 'lifting_scoremaps.npy'), synth.lifting_scoremaps(5, 2))
     np.save(os.path.join(d, 'lifting_hand_sides.npy'), synth.hand_sides(2))

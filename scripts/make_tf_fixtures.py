@@ -116,6 +116,22 @@ def main(argv=None, tf=None, eager=False, mods=None, set_empty_reduce=None):
                         image_crop_sub=crop[:, ::8, ::8, :], scale_crop=scale, center=center,
                         kp_crop=np.stack([general.detect_keypoints(sm256[i]) for i in range(len(sm256))]))
 
+    # ---- the full pipeline on a BATCH of 8 (nets/ColorHandPose3DNetwork.py:61-99; utils/general.py:210 only needs B < H, W):
+    #      BASELINE config 4's per-GPU shard in small -- the batch size from which the engine's F(4x4,3x3) kernel takes the trunk
+    #      layers, so this file holds the headline kernel directly to the reference's code.  Optional input.
+    if os.path.exists(inp('c4_images.npy')):
+        img, sides = np.load(inp('c4_images.npy')), np.load(inp('c4_hand_sides.npy'))
+        hand_scoremap, image_crop, scale_crop, center, kp_scoremap, coord3d, mask = run(
+            ColorHandPose3DNetwork, wfiles, full, dict(image=img, hand_side=sides, evaluation=true))
+        kps = np.stack([general.detect_keypoints(kp_scoremap[i]) for i in range(len(img))])
+        np.savez_compressed(out('c4_b8_inference.npz'), seed0=np.load(inp('c4_seed0.npy')), shape=np.array(img.shape[1:3]), hand_side=sides,
+                            hand_scoremap_sub=hand_scoremap[:, ::8, ::8, :],
+                            mask_packed=np.stack([np.packbits(mask[i, :, :, 0].astype(np.uint8)) for i in range(len(img))]),
+                            center=center, scale_crop=scale_crop, image_crop_sub=image_crop[:, ::8, ::8, :],
+                            scoremap32=kp_scoremap[:, ::8, ::8, :], scoremap256_sum=kp_scoremap.sum(axis=(1, 2), dtype=np.float64),
+                            keypoint_coord3d=coord3d, kp_crop=kps,
+                            kp_uv=np.stack([general.trafo_coords(kps[i], center[i:i + 1], scale_crop[i:i + 1], 256) for i in range(len(img))]))
+
     # ---- mask / bounding-box stage (utils/general.py:233-328) on engineered score maps --------------------------------
     cases = np.load(inp('mask_cases.npz'))
     d = {}

@@ -90,6 +90,17 @@ def test_oracle_matches_reference_code_fixtures(synth_weights):
         assert np.array_equal(o[4][0, ::8, ::8, :], g[k + 'scoremap32'])
         assert np.abs(o[5] - g[k + 'keypoint_coord3d']).max() < 1e-6
         assert np.array_equal(G.detect_keypoints(o[4][0]), g[k + 'kp_crop'])
+    # the batch of 8 (ref_c4_b8_inference.npz): the oracle run per image equals the reference's BATCHED run (two images here, for time)
+    g8 = np.load(os.path.join(GOLD, 'ref_c4_b8_inference.npz'))
+    img8 = synth.make_batch(int(g8['seed0']), 8, int(g8['shape'][0]), int(g8['shape'][1]))
+    for i in (1, 6):
+        taps = {}
+        o = N.inference(synth_weights, img8[i:i + 1], g8['hand_side'][i:i + 1], True, taps=taps)
+        assert np.array_equal(np.packbits(taps['hand_mask'][0, :, :, 0].astype(np.uint8)), g8['mask_packed'][i])
+        assert np.array_equal(o[3], g8['center'][i:i + 1]) and np.array_equal(o[2], g8['scale_crop'][i:i + 1])
+        assert np.array_equal(o[4][0, ::8, ::8, :], g8['scoremap32'][i])
+        assert np.abs(o[5][0] - g8['keypoint_coord3d'][i]).max() < 1e-6
+        assert np.array_equal(G.detect_keypoints(o[4][0]), g8['kp_crop'][i])
     m = np.load(os.path.join(GOLD, 'ref_mask_cases.npz'))
     for rid in ('inf', 'fltmax'):
         G.EMPTY_REDUCE = rid

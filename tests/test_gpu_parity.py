@@ -576,18 +576,24 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
 
 
 def test_full_pipeline_batch32_winograd_active(net, synth_weights):
-    """The bench workload shape (B=32, 320x320): at this size the 3x3 layers with Cout % 64 == 0 and the 7x7 layers run as
-    Winograd F(2x2,3x3).  EVERY image of the batch is checked against the oracle (two of them against its
-    float64-accumulating form, the rest against the float32 one), then the whole batch against the direct-kernel engine."""
+    """The bench workload shape (B=32, 320x320): at this size the default policy puts every 3x3 / stride-1 trunk layer with
+    Cout % 64 == 0 and the ten 7x7 layers on conv_wino4.hip (Winograd F(4x4,3x3), the headline kernel) -- asserted by kernel name
+    and by the engine's launch counter, so a silent fall-back to another kernel fails here.  EVERY image of the batch is checked
+    against the oracle (two of them against its float64-accumulating form, the rest against the float32 one), then the whole batch
+    against the direct-kernel engine."""
     from hand3d_amd.utils.general import EvalUtil
     img = synth.make_batch(3000, 32, 320, 320)
     hs = synth.hand_sides(32)
+    c0 = net.engine.counter('conv_wino4_launches')
     o = net.engine.infer_full(img, hs, want_mask=True)
+    assert net.engine.counter('conv_wino4_launches') - c0 >= 36, "the F(4x4,3x3) kernel did not take the trunk layers"
     net.engine.set_profiling(1)
     net.engine.infer_full(img, hs)
-    kernels = set(k for _, k, _, _, _ in net.engine.profile())
+    prof = net.engine.profile()
     net.engine.set_profiling(0)
-    assert any(k.startswith('conv_wino') for k in kernels), kernels
+    w4 = [n for n, k, _, _, _ in prof if k.startswith('conv_wino4_')]
+    assert len(w4) >= 36 and 'HandSegNet/conv3_2' in w4 and 'PoseNet2D/conv4_2' in w4 and 'PoseNet2D/conv6_3' in w4, sorted(set(k for _, k, _, _, _ in prof))
+    assert not [k for _, k, _, _, _ in prof if k.startswith(('conv_wino_', 'conv_wino2_'))], "a trunk layer fell back to an F(2x2,3x3) kernel"
     ev = EvalUtil()
     worst = dict(scoremap=0.0, kpmap=0.0, coord3d=0.0)
     undecidable = []

@@ -67,6 +67,44 @@ def test_reference_fixtures_full_pipeline_c1(net, gold):
     assert mean_epe < TOL_KP3D
 
 
+def test_reference_fixtures_batch8_on_the_headline_kernel(net, gold):
+    """One batch of 8 at 240x320 through the reference's inference() (BASELINE config 4's per-GPU shard in small; utils/general.py:210
+    only needs B < H, W): from this batch size on the engine's default policy runs the trunk layers on conv_wino4.hip, so these
+    fixtures -- written by executing nets/ColorHandPose3DNetwork.py:61-99 -- meet the F(4x4,3x3) kernel directly, not through the
+    oracle chain.  Gates as everywhere: mask / centre / scale / arg-max keypoints exact, heat-maps 1e-3, 3-D keypoints 1e-4."""
+    from hand3d_amd.utils.general import detect_keypoints, trafo_coords
+    if not os.path.exists(os.path.join(GOLD, 'ref_c4_b8_inference.npz')):
+        pytest.fail("tests/golden/ref_c4_b8_inference.npz is missing: scripts/make_ref_fixtures.py writes it")
+    try:
+        g = gold('c4_b8_inference.npz')
+    except FileNotFoundError:
+        pytest.skip("tf13_c4_b8_inference.npz absent (needs a TensorFlow 1.x box)")
+    H, W = [int(v) for v in g['shape']]
+    img = synth.make_batch(int(g['seed0']), 8, H, W)
+    hs = g['hand_side']
+    c0 = net.engine.counter('conv_wino4_launches')
+    o = net.engine.infer_full(img, hs, want_mask=True)
+    n4 = net.engine.counter('conv_wino4_launches') - c0
+    print("conv_wino4 launches for the batch of 8:", n4)
+    assert n4 >= 20, "the F(4x4,3x3) kernel did not run: this test would not be holding it to the reference"
+    for i in range(8):
+        assert np.array_equal(np.packbits(o['mask'][i].astype(np.uint8)), g['mask_packed'][i]), "image %d: hand mask differs" % i
+    assert np.array_equal(o['center'], g['center']) and np.array_equal(o['scale'], g['scale_crop'])
+    assert np.abs(o['scoremap'][:, ::8, ::8, :] - g['hand_scoremap_sub']).max() < TOL_HEATMAP
+    assert np.abs(o['crop'][:, ::8, ::8, :] - g['image_crop_sub']).max() < 1e-5
+    e_map = np.abs(o['kpmap'][:, ::8, ::8, :] - g['scoremap32']).max()
+    e_3d = np.abs(o['coord3d'] - g['keypoint_coord3d']).max()
+    print("batch of 8 vs reference-code fixtures: heat-maps %.2e, coord3d %.2e" % (e_map, e_3d))
+    assert e_map < TOL_HEATMAP and e_3d < TOL_KP3D
+    assert np.abs(o['kpmap'].sum(axis=(1, 2), dtype=np.float64) - g['scoremap256_sum']).max() < 65536 * 1e-5
+    od = net.engine.infer_full(img, hs, outputs=('kp_crop', 'kp_hw'))
+    for i in range(8):
+        kp = detect_keypoints(o['kpmap'][i])
+        assert np.array_equal(kp, g['kp_crop'][i]) and np.array_equal(od['kp_crop'][i], g['kp_crop'][i])
+        assert np.array_equal(trafo_coords(kp, o['center'][i:i + 1], o['scale'][i:i + 1], 256), g['kp_uv'][i])
+        assert np.array_equal(od['kp_hw'][i], g['kp_uv'][i])
+
+
 def test_reference_fixtures_inference2d_c3(net, gold):
     """BASELINE config 3 shape: inference2d on raw 320x320 frames."""
     from hand3d_amd.utils.general import detect_keypoints

@@ -111,38 +111,76 @@ __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, fl
     y3 = (d12 + 8.f * d34) + m5;
 }
 
-template <bool POOL, int NSUB, bool SPLITK>
-HP3D_KERNEL2(256, 1)
-void conv_wino4_kernel(const ConvParams p) {
-    static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
-    HP3D_DYN_SMEM(V);
-    int* tinfo = (int*)(V + 2 * W4_VBUF_FLOATS);       // [parity][0..31] output offset of tile t (-1: none), [32..63] edge flags
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = HP3D_READFIRSTLANE(tid >> 6);
-    const int ln = lane & 15, lq = lane >> 4;          // MFMA column (cout / tile in block) and k slot
-
-    const int TXn = p.tiles_x, TYn = p.tiles_y, per_img = TXn * TYn;
-    const int tile_blocks = (p.B * per_img + W4_TILES - 1) / W4_TILES;
-    const int ncy = p.Cout / W4_COUTS;
-    const int per_split = tile_blocks * ncy;
-    const int nitems = per_split * (SPLITK ? p.ksplit : 1);
-    auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) {      // same flattened band order as conv_wino.hip
+// tile / item geometry shared by the convolution kernel and the tail reduction
+struct W4Geom {
+    int TXn, TYn, per_img, tile_blocks, ncy;
+    __device__ __forceinline__ W4Geom(const ConvParams& p)
+        : TXn(p.tiles_x), TYn(p.tiles_y), per_img(p.tiles_x * p.tiles_y), tile_blocks((p.B * p.tiles_x * p.tiles_y + W4_TILES - 1) / W4_TILES),
+          ncy(p.Cout / W4_COUTS) {}
+    // flat tile id -> (image, tile row, tile column): bands of four tile rows, column-major inside a band (a block of 32 consecutive
+    // ids is a 4 x 8 tile patch where the grid allows), continuing into the next image
+    __device__ __forceinline__ void tile_decode(int id, int& tb, int& tyy, int& txx) const {
         tb = id / per_img;
         const int r = id - tb * per_img;
         const int band = r / (4 * TXn), rem = r - band * 4 * TXn;
         const int rows = min(4, TYn - 4 * band);
         txx = rem / rows;
         tyy = band * 4 + rem - txx * rows;
-    };
+    }
+    // item index (within one channel split) -> (cout block, tile block)
+    __device__ __forceinline__ void item_decode(int r, int& cy_, int& tb_) const {
+#if HP3D_W4_ORDER
+        // XCD-affine order: workgroup ids go round-robin over the 8 XCDs; within an XCD consecutive items are the cout blocks of ONE
+        // tile block, so its windows are fetched from the fabric once per XCD and re-read from that XCD's L2
+        if ((tile_blocks & 7) == 0) {
+            const int xcd = r & 7, j = r >> 3, tbq = j / ncy;
+            cy_ = j - tbq * ncy;
+            tb_ = tbq * 8 + xcd;
+            return;
+        }
+#endif
+        cy_ = r / tile_blocks;
+        tb_ = r - cy_ * tile_blocks;
+    }
+};
+constexpr int W4_PIECE_FLOATS = W4_TILES * 16 * W4_COUTS;       // raw 4x4 outputs of one item: [tile 32][pixel 16][cout 64] = 128 KB
+
+// TAIL (3x3 filters, no whole-launch channel split): the items of a launch are dealt round-robin to one workgroup per CU; a last round
+// that is not full (HandSegNet's 40x40 layers at B = 32: 800 items on 256 CUs = 3.125 rounds, paid as 4) is shared out stream-K
+// fashion: its `tail_items` items x nsteps channel steps are ONE run of item-steps, cut into equal runs of `tail_q` steps, one per
+// workgroup.  A run lies in one item or crosses into the next: at most two PIECES per workgroup, whose raw sums (the output
+// transform is linear) go to a compact scratch [workgroup][piece 2][tile][pixel][cout]; wino4_tail_reduce adds an item's pieces in
+// step order, + bias, activation (+ pool), and stores.  Deterministic; only the summation order of the tail items changes.
+template <bool POOL, int NSUB, bool SPLITK, bool TAIL>
+HP3D_KERNEL2(256, 1)
+void conv_wino4_kernel(const ConvParams p) {
+    static_assert(!(POOL && SPLITK), "the fused max-pool needs complete sums");
+    static_assert(!(TAIL && (SPLITK || NSUB != 1)), "tail pieces: plain 3x3 launches only");
+    constexpr bool VARSTEPS = SPLITK || TAIL;         // items own a RANGE of the channel steps
+    HP3D_DYN_SMEM(V);
+    int* tinfo = (int*)(V + 2 * W4_VBUF_FLOATS);       // [parity][0..31] output offset of tile t (-1: none), [32..63] edge flags
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = HP3D_READFIRSTLANE(tid >> 6);
+    const int ln = lane & 15, lq = lane >> 4;          // MFMA column (cout / tile in block) and k slot
+
+    const W4Geom geo(p);
+    const int per_split = geo.tile_blocks * geo.ncy;
+    const int nitems = per_split * (SPLITK ? p.ksplit : 1);
+    // TAIL: virtual item ids [0, nfull) are whole items; nfull + 2 w + j = piece j of workgroup w's run of the tail's item-steps
+    const int nfull = TAIL ? nitems - p.tail_items : nitems;
+    auto tile_decode = [&](int id, int& tb, int& tyy, int& txx) { geo.tile_decode(id, tb, tyy, txx); };
     const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
     // tile table.  Plain: offset of output (4 ty, 4 tx), flags = valid rows | valid columns << 4 (1..4 each).  Pooled: offset of
     // pooled output (2 ty, 2 tx), flags = bit 0: column 2 tx + 1 exists, bit 1: row 2 ty + 1 exists.
-    auto table_write = [&](int tblock, int parity, int kz) {
+    auto table_write = [&](int tblock, int parity, int kz, int piece) {
         if (tid < W4_TILES) {
             int tb, tyy, txx;
             tile_decode(tblock * W4_TILES + tid, tb, tyy, txx);
             int off = -1, fl = 0;
-            if (tb < p.B) {
+            if (TAIL && piece >= 0) {          // raw piece: every tile's 4x4 outputs, compact
+                off = piece * W4_PIECE_FLOATS + tid * (16 * W4_COUTS);
+                fl = 4 | (4 << 4);
+            } else if (tb < p.B) {
                 if (POOL) {
                     if (2 * tyy < Hs && 2 * txx < Ws) {
                         off = ((tb * Hs + 2 * tyy) * Ws + 2 * txx) * p.out_cs;
@@ -194,7 +232,7 @@ void conv_wino4_kernel(const ConvParams p) {
     };
     auto loader_shift = [&](int sub) { window_offsets(true, cb, cty, ctx_, sub); };
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
-    const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u);
+    const unsigned out_bytes = (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u;
 
     f32x2 d[36];
     auto window_fetch = [&](int soff) {
@@ -249,31 +287,49 @@ void conv_wino4_kernel(const ConvParams p) {
         for (int m = 0; m < 2; ++m) af[set][m] = *(const f32x4*)((const char*)V + base + (pl * W4_PLANE_FLOATS + m * 16 * W4_CK) * 4);
     };
 
-    auto split_of = [&](int it, int& kz, int& cy_, int& tb_) {
-        kz = SPLITK ? it / per_split : 0;
-        const int r = SPLITK ? it - kz * per_split : it;
-#if HP3D_W4_ORDER
-        // XCD-affine order: workgroup ids go round-robin over the 8 XCDs; within an XCD consecutive items are the cout blocks of ONE
-        // tile block, so its windows are fetched from the fabric once per XCD and re-read from that XCD's L2
-        if ((tile_blocks & 7) == 0) {
-            const int xcd = r & 7, j = r >> 3, tbq = j / ncy;
-            cy_ = j - tbq * ncy;
-            tb_ = tbq * 8 + xcd;
+    // virtual item id -> cout block, tile block, channel steps [s0_, s1_), piece slot (-1 = a whole item / a slice of the [ksplit] scratch)
+    auto split_of = [&](int it, int& kz, int& cy_, int& tb_, int& piece_, int& s0_, int& s1_) {
+        piece_ = -1;
+        kz = 0;
+        if (TAIL && it >= nfull) {
+            piece_ = it - nfull;
+            const int w = piece_ >> 1;
+            const int a = w * p.tail_q, b = min(a + p.tail_q, p.tail_items * nsteps);       // this workgroup's run of item-steps
+            const int i0 = a / nsteps;
+            if (piece_ & 1) { s0_ = 0; s1_ = b - (i0 + 1) * nsteps; geo.item_decode(nfull + i0 + 1, cy_, tb_); }
+            else { s0_ = a - i0 * nsteps; s1_ = min(nsteps, s0_ + b - a); geo.item_decode(nfull + i0, cy_, tb_); }
             return;
         }
-#endif
-        cy_ = r / tile_blocks;
-        tb_ = r - cy_ * tile_blocks;
+        kz = SPLITK ? it / per_split : 0;
+        geo.item_decode(SPLITK ? it - kz * per_split : it, cy_, tb_);
+        s0_ = SPLITK ? (kz * nsteps) / p.ksplit : 0;
+        s1_ = SPLITK ? ((kz + 1) * nsteps) / p.ksplit : nsteps;
     };
-    auto first_step_of = [&](int kz) { return SPLITK ? HP3D_READFIRSTLANE((kz * nsteps) / p.ksplit) : 0; };
+    // the workgroup's sequence of virtual items: blockIdx.x, + gridDim.x, ... below nfull, then (TAIL) the one or two pieces of its run
+    auto next_of = [&](int it) {
+        const int nx = it + (int)gridDim.x;
+        if (!TAIL) return nx < nitems ? nx : -1;
+        if (it < nfull && nx < nfull) return nx;
+        const int w = (int)blockIdx.x, a = w * p.tail_q, tot = p.tail_items * nsteps;
+        if (a >= tot) return -1;
+        const int b = min(a + p.tail_q, tot), i0 = a / nsteps;
+        if (it < nfull) return nfull + 2 * w;
+        if (it == nfull + 2 * w && b > (i0 + 1) * nsteps) return nfull + 2 * w + 1;      // the run crosses into the next item
+        return -1;
+    };
     int item = blockIdx.x;
-    int kz, cy, tblock;
-    split_of(item, kz, cy, tblock);
-    int s0 = first_step_of(kz), s1 = SPLITK ? first_step_of(kz + 1) : nsteps;
+    if (TAIL && item >= nfull) {                    // no whole item for this workgroup (a launch of less than one round): straight to its run
+        if ((int)blockIdx.x * p.tail_q >= p.tail_items * nsteps) return;
+        item = nfull + 2 * (int)blockIdx.x;
+    }
+    int kz, cy, tblock, piece, s0, s1;
+    split_of(item, kz, cy, tblock, piece, s0, s1);
+    if (VARSTEPS) { kz = HP3D_READFIRSTLANE(kz); cy = HP3D_READFIRSTLANE(cy); tblock = HP3D_READFIRSTLANE(tblock); piece = HP3D_READFIRSTLANE(piece);
+                    s0 = HP3D_READFIRSTLANE(s0); s1 = HP3D_READFIRSTLANE(s1); }
     const int sub0 = (NSUB > 1 && SPLITK) ? HP3D_READFIRSTLANE(s0 / csteps) : 0;
     int sub_cur = sub0;                           // block (i, j) = (sub_cur / 3, sub_cur % 3) of the 9x9 extension the current step belongs to
     loader_setup(tblock, true, sub0);
-    table_write(tblock, 0, kz);
+    table_write(tblock, 0, kz, piece);
     int wvoff = (cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
     window_fetch((s0 - sub0 * csteps) * ((HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4));
 #pragma unroll
@@ -283,10 +339,11 @@ void conv_wino4_kernel(const ConvParams p) {
     int cur = 0;
 
     for (int k = 0;; ++k) {
-        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0;
-        const int n_item = item + (int)gridDim.x;
+        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0, n_s1 = s1, n_piece = -1;
+        const int n_item = next_of(item);
+        const bool raw = TAIL && piece >= 0;          // this item is a tail piece: raw sums into the compact scratch
         const int cout = cy * W4_COUTS + wave * 16 + ln;
-        const float bias = SPLITK ? 0.f : p.bias[cout];
+        const float bias = (SPLITK || raw) ? 0.f : p.bias[cout];
 
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -296,7 +353,7 @@ void conv_wino4_kernel(const ConvParams p) {
             const int skip_b = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR(zb ? 1 : 0) : 0;
             const int skip_ab = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR((za || zb) ? 1 : 0) : 0;
             const int nvoff = lasts ? n_wvoff : wvoff;
-            const int nstep = lasts ? (SPLITK ? n_s0 : 0) : step + 1;
+            const int nstep = lasts ? (VARSTEPS ? n_s0 : 0) : step + 1;
             ab0 = cur * (W4_VBUF_FLOATS * 4) + va_lane;
             ab1 = ab0 + W4_HALF * W4_PLANE_FLOATS * 4;
             HP3D_OPAQUE_V(ab0);
@@ -305,7 +362,7 @@ void conv_wino4_kernel(const ConvParams p) {
             for (int t = 0; t < W4_ADEPTH - 1; ++t) a_fetch(t, t);
             const int nsub_ = NSUB == 1 ? 0 : SPLITK ? HP3D_READFIRSTLANE(nstep / csteps) : lasts ? 0 : (step + 1) / csteps;
             const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;
-            if (lasts) loader_setup(n_tblock, n_item < nitems, nsub_);
+            if (lasts) loader_setup(n_tblock, n_item >= 0, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
             const int wstep_b = (HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4;
             const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * wstep_b) : ncs * wstep_b;
@@ -346,15 +403,18 @@ void conv_wino4_kernel(const ConvParams p) {
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };
-        step_body(s0, std::true_type{});
-        {
-            const bool has_next = n_item < nitems;
-            if (has_next) split_of(n_item, n_kz, n_cy, n_tblock);
-            if (SPLITK) { n_kz = HP3D_READFIRSTLANE(n_kz); n_cy = HP3D_READFIRSTLANE(n_cy); n_tblock = HP3D_READFIRSTLANE(n_tblock); }
-            n_s0 = first_step_of(n_kz);
-            table_write(n_tblock, (k + 1) & 1, n_kz);
+        {   // the next item of this workgroup, known BEFORE the first step: an item may be a single step (a one-step tail piece), whose
+            // only step is also the one that prefetches the next item's first windows and weight fragments
+            const bool has_next = n_item >= 0;
+            if (has_next) split_of(n_item, n_kz, n_cy, n_tblock, n_piece, n_s0, n_s1);
+            if (VARSTEPS) { n_kz = HP3D_READFIRSTLANE(n_kz); n_cy = HP3D_READFIRSTLANE(n_cy); n_tblock = HP3D_READFIRSTLANE(n_tblock); n_piece = HP3D_READFIRSTLANE(n_piece);
+                            n_s0 = HP3D_READFIRSTLANE(n_s0); n_s1 = HP3D_READFIRSTLANE(n_s1); }
             n_wvoff = (n_cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
         }
+        step_body(s0, std::true_type{});
+        // (the tile table of the next item goes into the other parity only now: the barrier that ended the step above is what tells
+        //  that every wave has finished reading that parity in the PREVIOUS item's epilogue)
+        table_write(n_tblock, (k + 1) & 1, n_kz, n_piece);
         for (int step = s0 + 1; step < s1; ++step) step_body(step, std::false_type{});
 
         // ---- epilogue: Y = A^T M A per (tile, cout), bias + leaky-ReLU (+ 2x2 max-pool) + NHWC store; a channel split stores its
@@ -365,7 +425,10 @@ void conv_wino4_kernel(const ConvParams p) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 #endif
         const int* tab = tinfo + (k & 1) * 2 * W4_TILES;
-        const bool cok = cout < p.cout_store;
+        const bool cok = raw || cout < p.cout_store;
+        const int cout_off = raw ? wave * 16 + ln : cout;                // a piece holds the item's 64 couts only
+        const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(raw ? (float*)p.partial : p.out, raw ? 2u * gridDim.x * (unsigned)(W4_PIECE_FLOATS * 4) : out_bytes);
+        const int srow = raw ? 4 * W4_COUTS * 4 : Ws * p.out_cs * 4, scol = raw ? W4_COUTS * 4 : p.out_cs * 4;      // byte strides of the 4x4 block
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
 #pragma unroll
@@ -373,7 +436,7 @@ void conv_wino4_kernel(const ConvParams p) {
                 const int t = 16 * m + 4 * lq + r;          // MFMA row = Winograd tile
                 const int off = tab[t];
                 const int fl = tab[W4_TILES + t];
-                const int vo = (cok && off >= 0) ? (off + cout) * 4 : OOR;
+                const int vo = (cok && off >= 0) ? (off + cout_off) * 4 : OOR;
                 float z[6][4];                               // A^T M: along the plane rows a
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
@@ -385,7 +448,7 @@ void conv_wino4_kernel(const ConvParams p) {
                 for (int i = 0; i < 4; ++i) {
                     if (HP3D_W4_ABL & 512) { y[i][0] = z[0][i]; y[i][1] = z[1][i]; y[i][2] = z[2][i]; y[i][3] = z[3][i] + z[4][i] + z[5][i]; }
                     else w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
-                    if (!POOL) {
+                    if (!POOL && !raw) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float x = y[i][j] + bias;
@@ -394,7 +457,7 @@ void conv_wino4_kernel(const ConvParams p) {
                         }
                     }
                 }
-                if (POOL) {
+                if (POOL && !raw) {
 #pragma unroll
                     for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
@@ -415,15 +478,76 @@ void conv_wino4_kernel(const ConvParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(y[i][j]), "v"(j < vc ? vrow : OOR));
-                            else HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, (i * Ws + j) * p.out_cs * 4);
+                            else HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, i * srow + j * scol);
                         }
                     }
                 }
             }
         }
-        if (n_item >= nitems) break;
+        if (n_item < 0) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
-        if (SPLITK) { kz = n_kz; s0 = n_s0; s1 = first_step_of(n_kz + 1); }
+        if (VARSTEPS) { kz = n_kz; piece = n_piece; s0 = n_s0; s1 = n_s1; }
+    }
+}
+
+// Tail pieces -> outputs: thread = (tail item, tile, output pixel [pooled: pooled pixel], cout quad); the slices are added in slice order
+// (deterministic), then bias, leaky-ReLU (+ the 2x2 max of the tile's four pooling windows), float4 store.
+template <bool POOL>
+HP3D_KERNEL(256)
+void wino4_tail_reduce_kernel(const ConvParams p) {
+    const W4Geom geo(p);
+    const int nitems = geo.tile_blocks * geo.ncy, nfull = nitems - p.tail_items;
+    constexpr int PX = POOL ? 4 : 16;
+    const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
+    const long total = (long)p.tail_items * W4_TILES * PX * (W4_COUTS / 4);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(e % (W4_COUTS / 4));
+        long r = e / (W4_COUTS / 4);
+        const int px = (int)(r % PX); r /= PX;
+        const int t = (int)(r % W4_TILES);
+        const int ti = (int)(r / W4_TILES);
+        int cy, tblock, img, ty, tx;
+        geo.item_decode(nfull + ti, cy, tblock);
+        geo.tile_decode(tblock * W4_TILES + t, img, ty, tx);
+        if (img >= p.B) continue;
+        const int co = cy * W4_COUTS + c4 * 4;
+        // the pieces of tail item ti, in step order: workgroup w's run [w q, (w + 1) q) of the tail's item-steps meets the item's
+        // [ti S, (ti + 1) S); it is the run's first piece (slot 2 w) when the run starts inside the item, else its second (slot 2 w + 1)
+        const int S = p.Cin / W4_CK, q = p.tail_q;
+        const int w_lo = (ti * S) / q, w_hi = ((ti + 1) * S - 1) / q;
+        const float* src = p.partial + (size_t)t * (16 * W4_COUTS) + c4 * 4;
+        auto slot_of = [&](int w) { return (size_t)(2 * w + (w * q >= ti * S ? 0 : 1)) * W4_PIECE_FLOATS; };
+        const f32x4 bias = *(const f32x4*)(p.bias + co);
+        f32x4 res;
+        int oy, ox;
+        if (POOL) {
+            const int pi = px >> 1, pj = px & 1;
+            oy = 2 * ty + pi; ox = 2 * tx + pj;
+            f32x4 mx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int pix = (2 * pi + (qd >> 1)) * 4 + 2 * pj + (qd & 1);
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                for (int w = w_lo; w <= w_hi; ++w) a += *(const f32x4*)(src + slot_of(w) + pix * W4_COUTS);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mx[j] = qd == 0 ? a[j] : fmaxf(mx[j], a[j]);
+            }
+            res = mx + bias;                      // bias + activation after the max, like the fused epilogue (monotonic: same bits)
+        } else {
+            oy = 4 * ty + (px >> 2); ox = 4 * tx + (px & 3);
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            for (int w = w_lo; w <= w_hi; ++w) a += *(const f32x4*)(src + slot_of(w) + px * W4_COUTS);
+            res = a + bias;
+        }
+        if (oy >= Hs || ox >= Ws) continue;
+        if (p.act) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) res[j] = fmaxf(res[j], HP3D_LEAKY_SLOPE * res[j]);
+        }
+        float* dst = p.out + ((size_t)(img * Hs + oy) * Ws + ox) * p.out_cs + co;
+        if (co + 3 < p.cout_store) *(f32x4*)dst = res;
+        else
+            for (int j = 0; j < 4; ++j) if (co + j < p.cout_store) dst[j] = res[j];
     }
 }
 
@@ -499,15 +623,34 @@ int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, in
     return 1;
 }
 
-template <bool POOL, int NSUB, bool SPLITK>
+size_t conv_wino4_tail_floats() { return (size_t)2 * hp3d_num_cus() * W4_PIECE_FLOATS; }        // two pieces per workgroup
+
+// Tail plan: items = full rounds of one workgroup per CU + a remainder.  The remainder's rem x nsteps item-steps are shared out in equal
+// runs of q = ceil(rem x nsteps / CUs) steps (at least 2: a piece pays a whole epilogue), one run per workgroup.  Returns q (0 = no
+// tail pieces: the last round is full, or so nearly full that the reduction would cost more than the idle CUs).
+int conv_wino4_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items) {
+    if (tail_items) *tail_items = 0;
+    const long tiles = (long)B * ((Ho + 3) / 4) * ((Wo + 3) / 4);
+    const long items = (tiles + W4_TILES - 1) / W4_TILES * (Cout / W4_COUTS);
+    const int slots = hp3d_num_cus(), nsteps = Cin / W4_CK;
+    const int rem = (int)(items % slots);
+    if (rem == 0 || rem * 8 > slots * 7 || nsteps < 2) return 0;
+    int q = (int)(((long)rem * nsteps + slots - 1) / slots);
+    if (q < 2) q = 2;
+    if (q >= nsteps) return 0;                   // whole items per workgroup: nothing to cut
+    if (tail_items) *tail_items = rem;
+    return q;
+}
+
+template <bool POOL, int NSUB, bool SPLITK, bool TAIL>
 static void wino4_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
     static bool attr_done[64] = {};
-    auto k = conv_wino4_kernel<POOL, NSUB, SPLITK>;
+    auto k = conv_wino4_kernel<POOL, NSUB, SPLITK, TAIL>;
     if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W4_SMEM_BYTES);
     const long items = (tiles + W4_TILES - 1) / W4_TILES * (p.Cout / W4_COUTS) * (SPLITK ? p.ksplit : 1);
     const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU
-    dim3 grid((unsigned)(items < slots ? items : slots));
+    dim3 grid((unsigned)((items < slots && !(TAIL && p.tail_items > 0)) ? items : slots));
     HP3D_LAUNCH(k, grid, dim3(256), W4_SMEM_BYTES, s, p);
 }
 
@@ -526,12 +669,22 @@ int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
     if (p.ksplit > 1) {
         const int nsteps = p.nsub * p.Cin / W4_CK;
         if (pool || p.ksplit * 2 > nsteps || p.out_cs != p.Cout) return -1;
-        if (p.nsub == 9) wino4_launch_t<false, 9, true>(p, tiles, s); else wino4_launch_t<false, 1, true>(p, tiles, s);
+        if (p.nsub == 9) wino4_launch_t<false, 9, true, false>(p, tiles, s); else wino4_launch_t<false, 1, true, false>(p, tiles, s);
         return 0;
     }
     p.ksplit = 1;
-    if (p.nsub == 9) wino4_launch_t<false, 9, false>(p, tiles, s);
-    else if (pool) wino4_launch_t<true, 1, false>(p, tiles, s);
-    else wino4_launch_t<false, 1, false>(p, tiles, s);
+    p.tail_items = p.tail_q = 0;
+    if (p.nsub == 9) { wino4_launch_t<false, 9, false, false>(p, tiles, s); return 0; }
+    // 3x3: the same instantiation serves launches with and without tail pieces (tail_items = 0: every item is a whole item)
+    if (p.partial && p.partial_cap >= conv_wino4_tail_floats() && !(pool && (p.cout_store & 3)) && (p.out_cs & 3) == 0 && ((uintptr_t)p.out & 15) == 0)
+        p.tail_q = conv_wino4_tail_plan(p.Cin, p.Cout, p.Ho, p.Wo, p.B, &p.tail_items);
+    if (pool) wino4_launch_t<true, 1, false, true>(p, tiles, s);
+    else wino4_launch_t<false, 1, false, true>(p, tiles, s);
+    if (p.tail_items > 0) {
+        const long total = (long)p.tail_items * W4_TILES * (pool ? 4 : 16) * (W4_COUTS / 4);
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        if (pool) HP3D_LAUNCH(wino4_tail_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
+        else HP3D_LAUNCH(wino4_tail_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+    }
     return 0;
 }

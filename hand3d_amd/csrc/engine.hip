@@ -284,6 +284,8 @@ struct hp3d_ctx {
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
+    int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
+    long conv_wino4_tail_launches = 0;
     long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
     long graph_epoch = 0;      // bumped by anything a captured sequence depends on (allocations, weights, options)
@@ -591,6 +593,16 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                 ctx->col_floats = need;
             }
             p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
+        } else if (take4 && l.k == 3 && ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+            // an under-filled last round of items runs as channel slices, one piece per CU (conv_wino4.hip, TAIL): scratch for the raw sums
+            const size_t need = conv_wino4_tail_floats();
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+            p.partial = ctx->col; p.partial_cap = ctx->col_floats;
+            ++ctx->conv_wino4_tail_launches;
         }
         {
             const char* kn = take4 ? (l.k == 7 ? (wino2_ks > 1 ? "conv_wino4_f4x4_3x3_as7x7_splitk" : "conv_wino4_f4x4_3x3_as7x7")
@@ -1147,7 +1159,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1503,6 +1515,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     ++ctx->graph_epoch;             // captured launch sequences may depend on any option
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
+    if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
@@ -1993,6 +2006,10 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         if (op_ks2 > 1) {
             d_part = S.alloc<float>((size_t)op_ks2 * B * Ho * Wo * Cout); NN(ctx, d_part);
             p.out = d_part;
+        } else if (op4 && k == 3 && ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+            p.partial = S.alloc<float>(conv_wino4_tail_floats()); NN(ctx, p.partial);         // tail pieces (conv_wino4.hip, TAIL)
+            p.partial_cap = conv_wino4_tail_floats();
+            ++ctx->conv_wino4_tail_launches;
         }
         if (op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream))
             HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
@@ -2199,6 +2216,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
+    if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }

@@ -224,6 +224,10 @@ struct ConvParams {
     // packed weights (mode 1, as conv_first reads them) and bias; nullptr otherwise
     const float* wpk1 = nullptr;
     const float* bias1 = nullptr;
+    // conv_wino4.hip tail pieces (set by conv_wino4_launch from `partial` / `partial_cap`): the last, under-filled round of items
+    // (tail_items of them) is shared out in runs of tail_q channel steps per workgroup, raw sums to `partial`; 0 = off
+    int tail_items = 0, tail_q = 0;
+    size_t partial_cap = 0;   // floats available behind `partial` (conv_wino4 tail pieces need conv_wino4_tail_floats())
 };
 
 // ---- launchers implemented in the .hip files (all stream-ordered, no sync) -------------
@@ -263,6 +267,10 @@ size_t wino4_packed_floats(int k, int cin_pad, int cout_pad);
 void wino4_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit);
 int conv_wino4_launch(const ConvParams& p, int pool, hipStream_t s);
+// scratch (floats) the tail pieces of any conv_wino4 launch can need: two 32-tile x 64-cout blocks of raw 4x4 outputs per CU
+size_t conv_wino4_tail_floats();
+// > 0: conv_wino4_launch would share the last round of this layer out as tail pieces (given the scratch); channel steps per workgroup
+int conv_wino4_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);
 
 // debug cross-check (one thread per output element, obviously-correct loops)

@@ -103,11 +103,24 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_p
         ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]
         n_mfma = sum(o.startswith('v_mfma') for o in ops)
         assert n_mfma > 0, name
+        addr0 = {}
+        for i, l in enumerate(ins):
+            m = re.search(r'//\s*([0-9A-Fa-f]+):', l)
+            if m:
+                addr0[int(m.group(1), 16)] = i
+        first0 = min(addr0) if addr0 else 0
         for i, o in enumerate(ops):
             if o == 's_cbranch_execnz':
-                near = ops[max(0, i - 12):i + 1]
-                assert not any(x.startswith(('buffer_load', 'buffer_store', 'global_load')) for x in near), \
-                    "%s: waterfall loop around a memory instruction (s_cbranch_execnz at instruction %d)" % (name, i)
+                # a waterfall loop is TIGHT: readfirstlane, compare, s_and_saveexec, the memory instruction, s_xor exec, branch back over
+                # a dozen instructions.  (hipcc also ends a uniform `if` arm with s_cbranch_execnz as a plain jump to a far label: not this.)
+                m = re.search(r'<[^>]*\+0x([0-9a-fA-F]+)>', ins[i])
+                tgt = addr0.get(first0 + int(m.group(1), 16)) if m else None
+                if tgt is None:
+                    tgt = max(0, i - 12)                  # unknown target: the old, stricter window
+                if tgt < i and i - tgt <= 48:
+                    body = ops[tgt:i + 1]
+                    assert not any(x.startswith(('buffer_load', 'buffer_store', 'global_load')) for x in body), \
+                        "%s: waterfall loop around a memory instruction (s_cbranch_execnz at instruction %d)" % (name, i)
         # loops = backward branches; the innermost loop that issues MFMAs (the step / chunk loop) must not touch scratch
         # (the persistent per-item loop around them may: per-item addresses are allowed to live in scratch)
         addr = {}

@@ -448,3 +448,39 @@ def test_lift_fused_one_launch_lifting_stage_on_interpreter(emu_engine, synth_we
         assert np.abs(o[0] - r[0]).max() < 1e-5
     finally:
         emu_engine.set_option('lift_fused', 'auto')
+
+
+@pytest.mark.parametrize("case", [(1, 16, 32, 128, 256, 0), (1, 16, 32, 128, 256, 1), (4, 18, 22, 128, 64, 0), (4, 18, 22, 128, 64, 1), (7, 16, 32, 192, 64, 0),
+                                  # two tail items: the middle workgroup's run crosses from one into the other (two pieces); less than one round in all
+                                  (5, 16, 32, 128, 64, 0), (5, 16, 32, 128, 64, 1), (2, 16, 32, 128, 64, 0), (1, 16, 32, 64, 128, 1)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_winograd_f4x4_tail_pieces_on_interpreter(emu_engine, case):
+    """conv_wino4.hip's TAIL: the interpreter's "chip" has 3 CUs, so 4 or 7 work items are one / two full rounds + ONE item, 5 items
+    one round + TWO, 2 items less than a round.  The remainder's item-steps are shared out in equal runs, one per workgroup (a run
+    may cross from one item into the next: two pieces), raw 4x4 sums go to the compact scratch, wino4_tail_reduce adds an item's
+    pieces in step order (+ bias, leaky-ReLU, the pooled form, ragged edges, a tile block that runs past the last image).  The
+    counter proves the path ran; with the option off the same layer runs unsplit and both agree with the float64 oracle."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case) + 11)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('wino4', '1')
+    try:
+        outs = {}
+        for tail in ('1', '0'):
+            emu_engine.set_option('wino4_tail', tail)
+            n0, t0 = emu_engine.counter('conv_wino4_launches'), emu_engine.counter('conv_wino4_tail_launches')
+            outs[tail] = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+            assert emu_engine.counter('conv_wino4_launches') == n0 + 1
+            assert emu_engine.counter('conv_wino4_tail_launches') == t0 + (1 if tail == '1' else 0)
+            assert outs[tail].shape == r.shape and np.abs(outs[tail] - r).max() < 1e-4, (tail, np.abs(outs[tail] - r).max())
+        # same products, another summation order -- in the tail item only: everything outside it is bit-identical
+        diff = np.abs(outs['1'] - outs['0'])
+        assert diff.max() < 1e-4 and 0 < (diff > 0).mean() <= (1.0 if B * Cout <= 128 else 0.6), (diff.max(), (diff > 0).mean())
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino4_tail', '1')

@@ -172,6 +172,46 @@ def test_conv_winograd_two_workgroups_per_cu_7x7(gpu_engine, case):
     assert err < 5e-5
 
 
+@pytest.mark.parametrize("case", [(10, 64, 64, 256, 256, 0), (32, 40, 40, 512, 512, 0), (32, 80, 80, 256, 256, 1), (5, 126, 158, 128, 128, 0), (3, 40, 40, 512, 128, 0)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_conv_winograd_f4x4_tail_pieces(gpu_engine, case):
+    """conv_wino4.hip's TAIL (option wino4_tail, default on): a launch whose last round of work items is not full -- HandSegNet's 40x40
+    layers at B = 32 are 800 items on 256 CUs -- shares that round's item-steps out in equal runs, one per CU (a run may cross from one
+    item into the next), and wino4_tail_reduce adds an item's raw pieces in step order.  Shapes: a quarter round left, an eighth, a
+    pooled layer, more than half a round with ragged tiles, less than one round in all.  Against the same kernel with the option off
+    (only the tail items may differ, by summation order) and against conv_wino.hip (F(2x2,3x3), itself oracle-checked); deterministic;
+    the counter proves the path ran."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case) + 21)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    gpu_engine.set_option('wino4', '1')
+    gpu_engine.set_option('wino_splitk', '0')       # (a launch of less than one round would otherwise take the whole-launch channel split)
+    try:
+        t0 = gpu_engine.counter('conv_wino4_tail_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino4_tail_launches') == t0 + 1, "the launch has no tail pieces: wrong test shape for this chip"
+        assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, bool(pool))), "not deterministic"
+        gpu_engine.set_option('wino4_tail', '0')
+        y0 = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino4_tail_launches') == t0 + 2
+    finally:
+        gpu_engine.set_option('wino4_tail', '1')
+        gpu_engine.set_option('wino_splitk', '1')
+        gpu_engine.set_option('wino4', '0')
+    gpu_engine.set_option('conv_impl', 'winograd')
+    try:
+        r = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+        gpu_engine.set_option('wino4', 'auto')
+    d = np.abs(y - y0)
+    frac = float((d > 0).mean())
+    print("tail pieces %s: vs unsplit %.2e on %.1f %% of the outputs, vs F(2x2,3x3) %.2e" % (case, d.max(), 100 * frac, np.abs(y - r).max()))
+    assert y.shape == r.shape and d.max() < 1e-4 and 0 < frac < (1.01 if B * H < 200 else 0.5) and np.abs(y - r).max() < 2e-4
+
+
 W4_CASES = [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 17, 21, 32, 64, 0, 3), (1, 30, 40, 512, 512, 0, 3),
             (1, 32, 32, 256, 256, 0, 3), (2, 60, 80, 128, 256, 1, 3), (3, 10, 6, 16, 64, 1, 3), (16, 64, 64, 256, 256, 0, 3), (16, 128, 128, 128, 128, 1, 3),
             (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7),

@@ -1136,7 +1136,7 @@ int infer_full_chunked1(hp3d_ctx* ctx, int B, int H, int W, const float* image, 
 // persistent Winograd kernels leave CUs idle in their last round of work items (1600 items on 256 CUs = 6.25 rounds) and
 // between dependent launches: the other half's kernels fill exactly those holes.  Measured (profiles/r02_tuning_notes.md):
 // float32 B=32 320x320 1558 -> 1615 img/s, 240x320 +1.8 %, 480x640 +6.9 %, B=16 +4.5 %, B=64 +6.4 %, f16 trunks +2.1 %; four
-// streams of 8 images lose 8 % (too few items per launch) -- hence "auto" = 2 streams from 16 images per call, 1 below.
+// streams of 8 images lose 8 % (too few items per launch); round 3's "auto" was 2 streams from 16 images per call; round 4: see `ns` below.
 // Per-launch profiling and hipGraph replay keep one stream.  A half-batch may take another kernel plan than the whole
 // batch would (small-batch Winograd split-K): results equal the one-stream run to rounding, discrete decisions included.
 int kid_sync_state(hp3d_ctx* ctx) {
@@ -1170,7 +1170,11 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
                        float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
                        int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
     if (!ctx) return HP3D_ERR_ARG;
-    const int ns = ctx->nstreams >= 0 ? ctx->nstreams : (B >= 16 ? 2 : 1);
+    // "auto": two streams when each half still fills the persistent grids -- from 3 M input pixels per half.  Round 4 (tail pieces took the
+    // last-round quantisation out of the one-stream run; same box, float32, images/s one / two streams): B=32 320x320 2190 / 2115,
+    // B=16 1975 / 1787, B=8 1666 / 1372, B=32 240x320 2454 / 2408 -- one stream; B=64 320x320 (two chunks of 32) 2195 / 2292, B=32 480x640
+    // 989 / 1051, f16 B=128 480x640 3234 / 3321 -- two (profiles/r04_tuning_notes.md).
+    const int ns = ctx->nstreams >= 0 ? ctx->nstreams : ((long)(B / 2) * H * W >= 3000000L ? 2 : 1);
     if (ns < 2 || B < 2 || ctx->profiling || ctx->use_graph || ctx->conv_naive || ctx->shared_weights || !hand_side ||
         (!image && !image_u8) || kid_sync_state(ctx) != 0)
         return infer_full_chunked1(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center, kp_scoremap,

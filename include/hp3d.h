@@ -67,7 +67,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            shapes) | "naive" (debug cross-check kernel, never a fallback);
  *          "streams"      = "auto" (default) | "1" | "2": whole-path calls run the two halves of their batch concurrently
  *                            on two HIP streams (second arena, shared weights; fills the tail rounds of the persistent
- *                            kernels and the launch gaps).  auto = 2 from 16 images per call.  Results equal "1" to
+ *                            kernels and the launch gaps).  auto = 2 when each half has at least 3 M input pixels (B = 32 at
+ *                            480x640, two chunks of 32 at 320x320), else 1 (round 4: with "wino4_tail" the one-stream run no longer
+ *                            loses a partial last round, and halves of 16 images fill the chip worse).  Results equal "1" to
  *                            rounding (images are independent; a half may take the small-batch kernel plan);
  *                            profiling / graph replay use one stream.  The halves overlap on the device-pointer entry points
  *                            (hp3d_infer_full_dev ...); with HOST output buffers the first half's pageable device->host

@@ -63,7 +63,7 @@ static inline int hp3d_num_cus() { return 3; }     // small on purpose: persiste
 struct hp3d_rsrc_t { const char* base; unsigned bytes; };
 #define HP3D_MAKE_RSRC(ptr, bytes) hp3d_rsrc_t{(const char*)(ptr), (unsigned)(bytes)}
 static inline void hp3d_emu_buffer_lds16(hp3d_rsrc_t r, float* lds_wave_base, unsigned off, int lane) {
-    if (off + 16u <= r.bytes) memcpy(lds_wave_base + lane * 4, r.base + off, 16);
+    if (off < r.bytes && off + 16u <= r.bytes) memcpy(lds_wave_base + lane * 4, r.base + off, 16);      // (off + 16 may wrap: negative offsets)
     else memset(lds_wave_base + lane * 4, 0, 16);
 }
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) \

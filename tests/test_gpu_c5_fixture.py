@@ -66,9 +66,13 @@ def test_config_c5_f16_480x640_against_oracle_fixture(gpu_engine, synth_weights)
               "score maps %s, pipeline heat-map %.2e, coord3d %.2e (vs the float32 oracle %.2e), same crop on %d/%d images"
               % (e_small, flips, 100 * sure.mean(), ' / '.join('%.2e' % e for e in e_sm), e_kp, e_3d, e_3d_f32, len(same), n_img))
         assert e_small < TOL and max(e_sm) < TOL
-        assert len(same) >= 1, "no image took the oracle's crop: the mask stage disagrees with the fixture everywhere"
-        assert e_kp < TOL and e_3d < TOL
-        assert e_3d_f32 < 5e-3           # the configuration's own looser bar against the float32 path
+        # every image must take the oracle's crop (both do: the undecidable det pixels above do not reach a box edge); a silent
+        # divergence of one image would otherwise hide behind the other
+        assert len(same) == n_img, "an image took another crop than the oracle's: %r" % (sorted(set(range(n_img)) - set(same)),)
+        # gates = what this kernel set measures (MI355X, round 4: heat-maps 1.10e-3, coord3d 3.97e-4 vs the f16 oracle, 4.93e-4 vs the
+        # float32 oracle) x 3 for the 3-D keypoints; the heat-map / logit bar stays the half-precision tolerance (measured x 1.8)
+        assert e_kp < TOL and e_3d < 1.2e-3
+        assert e_3d_f32 < 1.5e-3         # the configuration's own looser bar against the float32 path (north star, float32: 1e-4)
         assert np.isfinite(o['coord3d']).all() and np.isfinite(o['kpmap']).all()
     finally:
         gpu_engine.set_option('f16_impl', 'h16')

@@ -425,6 +425,9 @@ void conv_wino4_kernel(const ConvParams p) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 #endif
         const int* tab = tinfo + (k & 1) * 2 * W4_TILES;
+        // every tile of the launch is a whole 4x4 block (pooled: 2x2) when the output extent is a multiple of 4 -- all trunk layers at the
+        // network's own sizes: the per-store edge selects then fall away (tiles beyond the batch carry no offset and stay out of range)
+        const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0 || raw) ? 1 : 0) != 0;
         const bool cok = raw || cout < p.cout_store;
         const int cout_off = raw ? wave * 16 + ln : cout;                // a piece holds the item's 64 couts only
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(raw ? (float*)p.partial : p.out, raw ? 2u * gridDim.x * (unsigned)(W4_PIECE_FLOATS * 4) : out_bytes);
@@ -457,31 +460,36 @@ void conv_wino4_kernel(const ConvParams p) {
                         }
                     }
                 }
-                if (POOL && !raw) {
+                auto store_tile = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;       // no edge selects: every store of the tile goes to `vo`
+                    if (POOL && !raw) {
 #pragma unroll
-                    for (int pi = 0; pi < 2; ++pi)
+                        for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
-                        for (int pj = 0; pj < 2; ++pj) {
-                            // bias + leaky-ReLU AFTER the max: x -> fl(x + bias) and the leaky-ReLU are monotonic, so
-                            // max_i act(fl(y_i + b)) == act(fl(max_i y_i + b)) bit for bit -- 4 instead of 16 per tile and cout
-                            float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
-                            if (p.act) v = fmaxf(v, HP3D_LEAKY_SLOPE * v);
-                            const bool ok = (pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2));
-                            if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(v), "v"(ok ? vo : OOR));
-                            else HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
-                        }
-                } else {
-                    const int vr = fl & 15, vc = fl >> 4;
+                            for (int pj = 0; pj < 2; ++pj) {
+                                // bias + leaky-ReLU AFTER the max: x -> fl(x + bias) and the leaky-ReLU are monotonic, so
+                                // max_i act(fl(y_i + b)) == act(fl(max_i y_i + b)) bit for bit -- 4 instead of 16 per tile and cout
+                                float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
+                                if (p.act) v = fmaxf(v, HP3D_LEAKY_SLOPE * v);
+                                const bool ok = FULL || ((pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2)));
+                                if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(v), "v"(ok ? vo : OOR));
+                                else HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
+                            }
+                    } else {
+                        const int vr = fl & 15, vc = fl >> 4;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int vrow = i < vr ? vo : OOR;
+                        for (int i = 0; i < 4; ++i) {
+                            const int vrow = (FULL || i < vr) ? vo : OOR;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(y[i][j]), "v"(j < vc ? vrow : OOR));
-                            else HP3D_BUFFER_STORE4(orsrc, y[i][j], j < vc ? vrow : OOR, i * srow + j * scol);
+                            for (int j = 0; j < 4; ++j) {
+                                if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(y[i][j]), "v"((FULL || j < vc) ? vrow : OOR));
+                                else HP3D_BUFFER_STORE4(orsrc, y[i][j], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
+                            }
                         }
                     }
-                }
+                };
+                if (!POOL && full) store_tile(std::true_type{});        // (the pooled epilogue measured slower with the second path: 4 stores per tile)
+                else store_tile(std::false_type{});
             }
         }
         if (n_item < 0) break;

@@ -153,6 +153,53 @@ void resize_bilinear_kernel(const float* x, int B, int H, int W, int C, int in_c
     }
 }
 
+// The same arithmetic, one workgroup per output ROW: its two source rows (2 x W x C floats) and the 3 x ow column terms sit in LDS, every
+// thread makes four consecutive values of the row's ow x C floats and stores them as 16 bytes.  For the 8x up-sampling of the key-point
+// score maps (32 x 32 x 21 -> 256 x 256 x 21, 176 MB per 32 images: the element kernel above spends its time on three integer divisions
+// and four gathered global loads per value, 1.6 TB/s) this is a streaming store.  Needs (ow x C) % 4 == 0 and 2 W C + 3 ow floats of LDS.
+HP3D_KERNEL(256)
+void resize_bilinear_rows_kernel(const float* x, int H, int W, int C, int in_cs, int oh, int ow, float* out, float inv_c) {
+    HP3D_DYN_SMEM(sm);
+    float* rows = sm;                             // [2][W][C]
+    int* cx0 = (int*)(sm + 2 * W * C);            // [ow] x0 * C, [ow] x1 * C
+    int* cx1 = cx0 + ow;
+    float* ctx = (float*)(cx1 + ow);              // [ow] tx
+    const int oy = blockIdx.x, b = blockIdx.y;
+    const float hscale = (float)H / (float)oh, wscale = (float)W / (float)ow;
+    int y0, y1; float ty;
+    resize_coord(oy, hscale, H, y0, y1, ty);
+    const float* xb = x + (size_t)b * H * W * in_cs;
+    for (int i = threadIdx.x; i < W * C; i += blockDim.x) {
+        const int px = (int)(((float)i + 0.5f) * inv_c), c = i - px * C;
+        rows[i] = xb[((size_t)y0 * W + px) * in_cs + c];
+        rows[W * C + i] = xb[((size_t)y1 * W + px) * in_cs + c];
+    }
+    for (int ox = threadIdx.x; ox < ow; ox += blockDim.x) {
+        int x0, x1; float tx;
+        resize_coord(ox, wscale, W, x0, x1, tx);
+        cx0[ox] = x0 * C; cx1[ox] = x1 * C; ctx[ox] = tx;
+    }
+    __syncthreads();
+    float* orow = out + ((size_t)b * oh + oy) * (size_t)ow * C;
+    const float* r0 = rows;
+    const float* r1 = rows + W * C;
+    for (int q4 = threadIdx.x * 4; q4 < ow * C; q4 += blockDim.x * 4) {
+        int ox = (int)(((float)q4 + 0.5f) * inv_c), c = q4 - ox * C;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int a0 = cx0[ox] + c, a1 = cx1[ox] + c;
+            const float tx = ctx[ox];
+            const float tl = r0[a0], tr = r0[a1], bl = r1[a0], br = r1[a1];
+            const float top = tl + (tr - tl) * tx;
+            const float bot = bl + (br - bl) * tx;
+            v[e] = top + (bot - top) * ty;
+            if (++c == C) { c = 0; ++ox; }
+        }
+        *(f32x4*)(orow + q4) = v;
+    }
+}
+
 // Input pre-processing on device: uint8 image -> `x/255 - 0.5` (data/BinaryDbReader.py:182,
 // run.py:59) -> tf.image.resize_images to the network size (eval_full.py:50, eval2d.py:53), fused:
 // 4x less H2D traffic, no float image round trip.  Same float32 op order as the oracle (bit-exact).
@@ -742,6 +789,13 @@ void avgpool8_launch(const float* x, int B, int H, int W, int C, float* out, int
 void resize_bilinear_launch(const float* x, int B, int H, int W, int C, int in_cs, int oh, int ow, float* out,
                             hipStream_t s) {
     const long total = (long)B * oh * ow * C;
+    const size_t row_lds = ((size_t)2 * W * C + (size_t)3 * ow) * 4;
+    // (exact px = i / C from the float reciprocal needs i < 2^20 or so: W x C and ow x C are far below)
+    if ((ow * C) % 4 == 0 && ((uintptr_t)out & 15) == 0 && row_lds <= 60 * 1024 && (long)ow * C < (1L << 20) && (long)W * C < (1L << 20) && B <= 65535 &&
+        oh >= 4 * H) {
+        HP3D_LAUNCH(resize_bilinear_rows_kernel, dim3(oh, B), dim3(256), row_lds, s, x, H, W, C, in_cs, oh, ow, out, 1.0f / (float)C);
+        return;
+    }
     if (total < (1L << 31)) {
         auto k32 = resize_bilinear_kernel<unsigned>;
         HP3D_LAUNCH(k32, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, s, x, B, H, W, C, in_cs, oh, ow, out);

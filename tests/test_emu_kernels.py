@@ -37,7 +37,11 @@ def test_glue_kernels_on_interpreter(emu_engine):
     x = rng.standard_normal((1, 16, 24, 3)).astype(np.float32)
     assert np.abs(e.avgpool8(x) - T.avg_pool_8x8(x)).max() < 1e-6
     x = rng.standard_normal((2, 5, 7, 3)).astype(np.float32)
-    assert np.array_equal(e.resize_bilinear(x, 40, 56), T.resize_bilinear_legacy(x, 40, 56))
+    assert np.array_equal(e.resize_bilinear(x, 40, 56), T.resize_bilinear_legacy(x, 40, 56))      # (one workgroup per output row: glue.hip rows kernel)
+    x21 = rng.standard_normal((2, 8, 8, 21)).astype(np.float32)                                  # the key-point maps' shape class: 8x, 21 channels
+    assert np.array_equal(e.resize_bilinear(x21, 64, 64), T.resize_bilinear_legacy(x21, 64, 64))
+    assert np.array_equal(e.resize_bilinear(x, 41, 57), T.resize_bilinear_legacy(x, 41, 57))      # 57 x 3 values per row: the element kernel
+    assert np.array_equal(e.resize_bilinear(x, 9, 12), T.resize_bilinear_legacy(x, 9, 12))        # small factor: the element kernel
     img = rng.uniform(-.5, .5, (3, 40, 56, 3)).astype(np.float32)
     c = np.array([[20, 30], [5, 50], [39.5, 2]], np.float32)
     s = np.array([5.0, 1.3, 0.25], np.float32)

@@ -33,10 +33,21 @@
 #define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
 #endif
 
+#ifndef HP3D_W4_PAIRS
+#define HP3D_W4_PAIRS 1
+#endif
+#ifndef HP3D_W4_TIMING
+#define HP3D_W4_TIMING 0         // 1: diagnostic build -- every wave sums shader-clock intervals of its steps (planes 0..28 | window wait +
+#endif                           // transform | planes 30..35 | barrier | epilogue) into w4_timing[]; conv_wino4_launch prints them (profiles/r04_tuning_notes.md)
 #ifndef HP3D_W4_ORDER
 #define HP3D_W4_ORDER 1            // 1: XCD-affine item order (conv3_2 -6 %), 0: cout-block-major like conv_wino.hip
 #endif
 #define W4_WLOAD HP3D_BUFFER_LOAD8
+
+#if HP3D_W4_TIMING
+__device__ unsigned long long w4_timing[8];
+#define W4_CLOCK() __builtin_readcyclecounter()
+#endif
 
 namespace {
 
@@ -132,12 +143,20 @@ struct W4Geom {
 #if HP3D_W4_ORDER
         // XCD-affine order: workgroup ids go round-robin over the 8 XCDs; within an XCD consecutive items are the cout blocks of ONE
         // tile block, so its windows are fetched from the fabric once per XCD and re-read from that XCD's L2
-        if ((tile_blocks & 7) == 0) {
+        // (round 4: any tile-block count -- the whole groups of eight tile blocks in that order, the up to seven left over behind them, still
+        //  cout block innermost.  Before, a count that is not a multiple of 8 fell back to the cout-block-major order: B = 24 at 320x320,
+        //  300 tile blocks, ran 6 % slower on one stream than as two halves.)
+        const int aff = (tile_blocks >> 3) * 8 * ncy;
+        if (r < aff) {
             const int xcd = r & 7, j = r >> 3, tbq = j / ncy;
             cy_ = j - tbq * ncy;
             tb_ = tbq * 8 + xcd;
-            return;
+        } else {
+            const int q = r - aff, tbi = q / ncy;
+            cy_ = q - tbi * ncy;
+            tb_ = (tile_blocks & ~7) + tbi;
         }
+        return;
 #endif
         cy_ = r / tile_blocks;
         tb_ = r - cy_ * tile_blocks;
@@ -338,6 +357,9 @@ void conv_wino4_kernel(const ConvParams p) {
     __syncthreads();
     int cur = 0;
 
+#if HP3D_W4_TIMING
+    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, t_mark = W4_CLOCK();
+#endif
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0, n_s1 = s1, n_piece = -1;
         const int n_item = next_of(item);
@@ -354,6 +376,9 @@ void conv_wino4_kernel(const ConvParams p) {
             const int skip_ab = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR((za || zb) ? 1 : 0) : 0;
             const int nvoff = lasts ? n_wvoff : wvoff;
             const int nstep = lasts ? (VARSTEPS ? n_s0 : 0) : step + 1;
+#if HP3D_W4_TIMING
+            { const unsigned long long t = W4_CLOCK(); tsum[4] += t - t_mark; t_mark = t; }      // (item switch / epilogue / step prologue)
+#endif
             ab0 = cur * (W4_VBUF_FLOATS * 4) + va_lane;
             ab1 = ab0 + W4_HALF * W4_PLANE_FLOATS * 4;
             HP3D_OPAQUE_V(ab0);
@@ -366,40 +391,93 @@ void conv_wino4_kernel(const ConvParams p) {
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
             const int wstep_b = (HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4;
             const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * wstep_b) : ncs * wstep_b;
+            // The plane as four PAIRS of MFMAs (one k quad, both tile halves) with ONE of the plane's other instructions after each: the next
+            // plane's A fragments | window load | window load | the weight fragment for the slot this plane releases.  Each issues under the
+            // 64 matrix-core cycles of the pair in front of it; as one block of eight with everything at the plane boundary the wave spent
+            // 40 (windows in L2) to 80 (windows cold) idle matrix-core cycles per plane issuing them (section 4 of the round-4 log).
+            // 7x7 filters keep the block form: their skip test would run four times per plane (measured 2-3 % slower).
 #pragma unroll
             for (int pl = 0; pl < W4_NP; ++pl) {
-                HP3D_SCHED_BARRIER();
-                if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
-                // the eight MFMAs of the plane (two tile halves alternating: 40-cycle dependent latency vs 32-cycle issue) as ONE
-                // statement that pins the accumulators' register file: planes 0..31 in the 256 AGPRs, planes 32..35 in arch VGPRs.
-                // 7x7 filters: in the edge blocks of the zero-extended 9x9 filter (i = 2 / j = 2: one filter row / column of three)
-                // G g G^T has a zero row a = 5 / column b = 5: those planes' MFMAs are skipped (289 instead of 324 plane-steps).
-                const int skip = (NSUB == 9 && !FIRST) ? ((pl / 6 == 5 && pl % 6 == 5) ? skip_ab : pl / 6 == 5 ? skip_a : pl % 6 == 5 ? skip_b : 0) : 0;
-                if (FIRST) {
-                    if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_FIRST("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
-                    else HP3D_MFMA16_PLANE_FIRST("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
+                if (HP3D_W4_PAIRS && NSUB == 1) {
+                    const int skip = (NSUB == 9 && !FIRST) ? ((pl / 6 == 5 && pl % 6 == 5) ? skip_ab : pl / 6 == 5 ? skip_a : pl % 6 == 5 ? skip_b : 0) : 0;
+                    const int as = pl % W4_ADEPTH, bs = pl % W4_RING;
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        HP3D_SCHED_BARRIER();
+                        if (FIRST && e == 0) {
+                            if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PAIR_FIRST("a", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e]);
+                            else HP3D_MFMA16_PAIR_FIRST("v", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e]);
+                        } else if (NSUB == 9 && !FIRST) {
+                            if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PAIR_UNLESS("a", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e], skip);
+                            else HP3D_MFMA16_PAIR_UNLESS("v", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e], skip);
+                        } else {
+                            if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PAIR("a", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e]);
+                            else HP3D_MFMA16_PAIR("v", M[pl][0], M[pl][1], af[as][0][e], af[as][1][e], bq[bs][e]);
+                        }
+                        HP3D_SCHED_BARRIER();
+                        if (e == 0) {
+                            if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
+                        } else if (e == 3) {
+                            // weight prefetch W4_RING planes ahead into the slot this plane just released
+                            const int t = pl + W4_RING;
+                            if (HP3D_W4_ABL & 8) {}
+                            else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                            else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
+                        } else if (!(HP3D_W4_ABL & 2)) {
+                            static_assert(W4_WPP == 2, "one window load behind each of the two middle pairs");
+                            const int we = pl * 2 + (e - 1);
+                            if (we < 36) d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                        }
+                    }
                 } else {
-                    if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_UNLESS("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
-                    else HP3D_MFMA16_PLANE_UNLESS("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
-                }
-                // weight prefetch W4_RING planes ahead into the slot this plane just released
-                const int t = pl + W4_RING;
-                if (HP3D_W4_ABL & 8) {}
-                else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
-                else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
-                if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
-#pragma unroll
-                    for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
-                        const int e = pl * W4_WPP + j;
-                        d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
+                    HP3D_SCHED_BARRIER();
+                    if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
+                    // the eight MFMAs of the plane (two tile halves alternating: 40-cycle dependent latency vs 32-cycle issue) as ONE
+                    // statement that pins the accumulators' register file: planes 0..31 in the 256 AGPRs, planes 32..35 in arch VGPRs.
+                    // 7x7 filters: in the edge blocks of the zero-extended 9x9 filter (i = 2 / j = 2: one filter row / column of three)
+                    // G g G^T has a zero row a = 5 / column b = 5: those planes' MFMAs are skipped (289 instead of 324 plane-steps).
+                    const int skip = (NSUB == 9 && !FIRST) ? ((pl / 6 == 5 && pl % 6 == 5) ? skip_ab : pl / 6 == 5 ? skip_a : pl % 6 == 5 ? skip_b : 0) : 0;
+                    if (FIRST) {
+                        if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_FIRST("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
+                        else HP3D_MFMA16_PLANE_FIRST("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING]);
+                    } else {
+                        if (pl < W4_AGPR_PLANES) HP3D_MFMA16_PLANE_UNLESS("a", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
+                        else HP3D_MFMA16_PLANE_UNLESS("v", M[pl][0], M[pl][1], af[pl % W4_ADEPTH][0], af[pl % W4_ADEPTH][1], bq[pl % W4_RING], skip);
+                    }
+                    // weight prefetch W4_RING planes ahead into the slot this plane just released
+                    const int t = pl + W4_RING;
+                    if (HP3D_W4_ABL & 8) {}
+                    else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                    else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
+                    if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
+    #pragma unroll
+                        for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
+                            const int e = pl * W4_WPP + j;
+                            d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
+                        }
                     }
                 }
                 if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) {
+#if HP3D_W4_TIMING
+                    { const unsigned long long t = W4_CLOCK(); tsum[0] += t - t_mark; t_mark = t; }
+                    // the windows are in once at most the weight fragments issued behind the last window load (planes 36 / WPP .. TRANSFORM_AT) are out
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W4_TRANSFORM_AT + 1 - 36 / W4_WPP) : "memory");
+                    { const unsigned long long t = W4_CLOCK(); tsum[5] += t - t_mark; t_mark = t; }
+#endif
                     transform_commit(cur ^ 1);
+#if HP3D_W4_TIMING
+                    { const unsigned long long t = W4_CLOCK(); tsum[1] += t - t_mark; t_mark = t; }
+#endif
                 }
             }
             HP3D_SCHED_BARRIER();
+#if HP3D_W4_TIMING
+            { const unsigned long long t = W4_CLOCK(); tsum[2] += t - t_mark; t_mark = t; }
+#endif
             if (!(HP3D_W4_ABL & 4)) __syncthreads();             // V[cur^1] complete, V[cur] free
+#if HP3D_W4_TIMING
+            { const unsigned long long t = W4_CLOCK(); tsum[3] += t - t_mark; t_mark = t; }
+#endif
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };
@@ -492,6 +570,16 @@ void conv_wino4_kernel(const ConvParams p) {
                 else store_tile(std::false_type{});
             }
         }
+#if HP3D_W4_TIMING
+        if (n_item < 0) {
+            const unsigned long long t = W4_CLOCK();
+            tsum[4] += t - t_mark;
+            if (lane == 0) {
+                for (int i = 0; i < 6; ++i) atomicAdd(&w4_timing[i], tsum[i]);
+                atomicAdd(&w4_timing[6], 1ull);
+            }
+        }
+#endif
         if (n_item < 0) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
         if (VARSTEPS) { kz = n_kz; piece = n_piece; s0 = n_s0; s1 = n_s1; }
@@ -664,6 +752,20 @@ static void wino4_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
 
 // pin.ksplit > 1: pin.out must be the partial-sum scratch [ksplit][B*Ho*Wo][Cout] with out_cs = cout_store = Cout; the caller runs
 // conv_splitk_reduce afterwards (bias + activation happen there).
+#if HP3D_W4_TIMING
+static void w4_timing_report(const ConvParams& p, hipStream_t s, const char* what) {
+    unsigned long long h[8] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(w4_timing), sizeof(h));
+    if (h[6]) {
+        const double w = (double)h[6];
+        fprintf(stderr, "w4_timing %s Cin %d Cout %d %dx%d B %d: per wave (cycles) planes 0..28 %.0f | window wait %.0f | transform %.0f | planes 30..35 %.0f | barrier %.0f | "
+                        "between steps / epilogue %.0f | waves %.0f\n", what, p.Cin, p.Cout, p.Ho, p.Wo, p.B, h[0] / w, h[5] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, w);
+    }
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(w4_timing), z, sizeof(z));
+}
+#endif
 int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
     const long kso = pin.ksplit > 1 ? pin.ksplit : 1;
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || kso * pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
@@ -678,16 +780,28 @@ int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
         const int nsteps = p.nsub * p.Cin / W4_CK;
         if (pool || p.ksplit * 2 > nsteps || p.out_cs != p.Cout) return -1;
         if (p.nsub == 9) wino4_launch_t<false, 9, true, false>(p, tiles, s); else wino4_launch_t<false, 1, true, false>(p, tiles, s);
+#if HP3D_W4_TIMING
+        w4_timing_report(p, s, p.nsub == 9 ? "7x7 split" : "3x3 split");
+#endif
         return 0;
     }
     p.ksplit = 1;
     p.tail_items = p.tail_q = 0;
-    if (p.nsub == 9) { wino4_launch_t<false, 9, false, false>(p, tiles, s); return 0; }
+    if (p.nsub == 9) {
+        wino4_launch_t<false, 9, false, false>(p, tiles, s);
+#if HP3D_W4_TIMING
+        w4_timing_report(p, s, "7x7");
+#endif
+        return 0;
+    }
     // 3x3: the same instantiation serves launches with and without tail pieces (tail_items = 0: every item is a whole item)
     if (p.partial && p.partial_cap >= conv_wino4_tail_floats() && !(pool && (p.cout_store & 3)) && (p.out_cs & 3) == 0 && ((uintptr_t)p.out & 15) == 0)
         p.tail_q = conv_wino4_tail_plan(p.Cin, p.Cout, p.Ho, p.Wo, p.B, &p.tail_items);
     if (pool) wino4_launch_t<true, 1, false, true>(p, tiles, s);
     else wino4_launch_t<false, 1, false, true>(p, tiles, s);
+#if HP3D_W4_TIMING
+    w4_timing_report(p, s, pool ? "3x3 pool" : "3x3");
+#endif
     if (p.tail_items > 0) {
         const long total = (long)p.tail_items * W4_TILES * (pool ? 4 : 16) * (W4_COUTS / 4);
         const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -83,6 +83,28 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  : "v"((a0)[0]), "v"((a0)[1]), "v"((a0)[2]), "v"((a0)[3]), "v"((a1)[0]), "v"((a1)[1]), "v"((a1)[2]),   \
                    "v"((a1)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]), "s"(skip)                     \
                  : "scc")
+// the same plane as four statements of two MFMAs (both tile halves of one k quad e): between them the kernel places the plane's loads ONE
+// PER GAP, so that each issues under the 64 matrix-core cycles of a pair instead of all of them queueing at the plane boundary
+// (profiles/r04_tuning_notes.md section 4: the boundary gap cost 40-80 idle cycles per plane)
+#define HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, skip)                                                \
+    asm volatile("s_cmp_lg_u32 %5, 0\n\t"                                                                          \
+                 "s_cbranch_scc1 .Lhp3d_skip%=\n\t"                                                                \
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %1, %3, %4, %1\n"                                                          \
+                 ".Lhp3d_skip%=:"                                                                                   \
+                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
+                 : "v"(a0e), "v"(a1e), "v"(be), "s"(skip)                                                           \
+                 : "scc")
+#define HP3D_MFMA16_PAIR(REG, acc0, acc1, a0e, a1e, be)                                                             \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %1, %3, %4, %1"                                                             \
+                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
+                 : "v"(a0e), "v"(a1e), "v"(be))
+#define HP3D_MFMA16_PAIR_FIRST(REG, acc0, acc1, a0e, a1e, be)                                                       \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, 0\n\t"                                                        \
+                 "v_mfma_f32_16x16x4_f32 %1, %3, %4, 0"                                                              \
+                 : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
+                 : "v"(a0e), "v"(a1e), "v"(be))
 // the first step of an item: the accumulators start from the inline constant 0 (never skipped)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                                                         \
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, 0\n\t"                                                       \

@@ -142,6 +142,20 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
             }                                                                     \
     } while (0)
 #define HP3D_MFMA16_PLANE_UNLESS(REG, acc0, acc1, a0, a1, b4, skip) HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, skip)
+#define HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, skip)                  \
+    do {                                                                              \
+        if (!(skip)) {                                                                \
+            (acc0) = hp3d_emu_mfma_16x16x4((a0e), (be), (acc0));                      \
+            (acc1) = hp3d_emu_mfma_16x16x4((a1e), (be), (acc1));                      \
+        }                                                                             \
+    } while (0)
+#define HP3D_MFMA16_PAIR(REG, acc0, acc1, a0e, a1e, be) HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, 0)
+#define HP3D_MFMA16_PAIR_FIRST(REG, acc0, acc1, a0e, a1e, be)                         \
+    do {                                                                              \
+        const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                        \
+        (acc0) = _z; (acc1) = _z;                                                     \
+        HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, 0);                    \
+    } while (0)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                      \
     do {                                                                          \
         const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                    \

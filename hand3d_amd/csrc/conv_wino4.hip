@@ -82,6 +82,21 @@ constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: th
 #endif
 constexpr int W4_TRANSFORM_AT = HP3D_W4_TAT;       // the plane under which the next step's windows are transformed
 
+// ISSUE ORDER of the 36 window loads of a step.  Window element (r, c) of every tile is the pixel (4 ty + r - 1, 4 tx + c - 1): the elements
+// (r, c), (r + 4, c), (r, c + 4), (r + 4, c + 4) of neighbouring tiles are the SAME pixels (the 6x6 windows overlap by two), i.e. the same
+// cache lines asked for by other lanes.  Issued in row-major order those requests lie up to 12 planes (3000 cycles) apart and the 32 KB L1,
+// through which ~300 KB stream per step, has dropped the line in between: every window line is filled up to four times.  Issued CLASS BY
+// CLASS ((r mod 4, c mod 4): 16 classes of 4 / 2 / 1 elements) the repeats follow within a plane or two and hit the line (or its pending
+// fill).  HP3D_W4_ISSUE=0: row-major (round 3).
+#ifndef HP3D_W4_ISSUE
+#define HP3D_W4_ISSUE 1
+#endif
+#if HP3D_W4_ISSUE
+#define W4_ISSUE_ELEM(k) ((int[36]){0, 4, 24, 28, 1, 5, 25, 29, 2, 26, 3, 27, 6, 10, 30, 34, 7, 11, 31, 35, 8, 32, 9, 33, 12, 16, 13, 17, 14, 15, 18, 22, 19, 23, 20, 21}[(k)])
+#else
+#define W4_ISSUE_ELEM(k) (k)
+#endif
+
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
 __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }
 
@@ -425,8 +440,10 @@ void conv_wino4_kernel(const ConvParams p) {
                             else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
                         } else if (!(HP3D_W4_ABL & 2)) {
                             static_assert(W4_WPP == 2, "one window load behind each of the two middle pairs");
-                            const int we = pl * 2 + (e - 1);
-                            if (we < 36) d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                            if (pl * 2 + (e - 1) < 36) {
+                                const int we = W4_ISSUE_ELEM(pl * 2 + (e - 1) < 36 ? pl * 2 + (e - 1) : 0);
+                                d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                            }
                         }
                     }
                 } else {
@@ -452,7 +469,7 @@ void conv_wino4_kernel(const ConvParams p) {
                     if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
     #pragma unroll
                         for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
-                            const int e = pl * W4_WPP + j;
+                            const int e = W4_ISSUE_ELEM(pl * W4_WPP + j);
                             d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
                         }
                     }

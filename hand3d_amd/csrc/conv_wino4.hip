@@ -439,10 +439,14 @@ void conv_wino4_kernel(const ConvParams p) {
                             else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
                             else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
                         } else if (!(HP3D_W4_ABL & 2)) {
-                            static_assert(W4_WPP == 2, "one window load behind each of the two middle pairs");
-                            if (pl * 2 + (e - 1) < 36) {
-                                const int we = W4_ISSUE_ELEM(pl * 2 + (e - 1) < 36 ? pl * 2 + (e - 1) : 0);
-                                d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                            static_assert(W4_WPP % 2 == 0, "the plane's window loads go behind its two middle pairs, half each");
+#pragma unroll
+                            for (int j = 0; j < W4_WPP / 2; ++j) {
+                                const int wk = pl * W4_WPP + (e - 1) * (W4_WPP / 2) + j;
+                                if (wk < 36) {
+                                    const int we = W4_ISSUE_ELEM(wk < 36 ? wk : 0);
+                                    d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                                }
                             }
                         }
                     }

@@ -89,6 +89,43 @@ def _kernel_disassembly(tmp_path):
     return kernels
 
 
+def test_fp_contraction_is_confined_to_the_winograd_f4x4_kernel(tmp_path):
+    """The build is `-ffp-contract=off` (the glue kernels restate float32 arithmetic of the reference OP BY OP: box, interpolation and
+    arg-max coordinates feed discontinuous decisions); one file, conv_wino4.hip, is built with `-ffp-contract=fast` for its transform
+    arithmetic.  Held here: (a) the per-file flag table names that file only and the global flags switch contraction off; (b) the SHIPPED
+    code object's glue kernels contain exactly the fused multiply-adds of a fresh `-ffp-contract=off` compile of glue.hip (IEEE division and
+    integer division expand to FMAs by themselves: those are the only ones), while a `-ffp-contract=fast` compile of the same file has MORE
+    of them in the interpolation kernels -- i.e. the check would see a leaked flag."""
+    from hand3d_amd import build as hb
+    assert '-ffp-contract=off' in hb.FLAGS and not any('contract=fast' in f for f in hb.FLAGS)
+    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip'}, "a second file with its own floating-point flags: extend this test before adding it"
+    assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip']
+    pat = re.compile(r'seg_upsample_softmax|seg_softmax|mask_grow|crop_and_resize|resize_bilinear|preprocess_u8|kp_detect|argmax2d')
+    fused = re.compile(r'v_(fma|fmac|mad|pk_fma)_f32')
+
+    def counts_from_asm(extra):
+        out = str(tmp_path / ('glue_%s.s' % ('fast' if extra else 'off')))
+        subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')] + hb.FLAGS + extra + ['-S', '--cuda-device-only', os.path.join(hb.CSRC, 'glue.hip'), '-o', out],
+                              stderr=subprocess.DEVNULL)
+        res, cur = {}, None
+        for line in open(out):
+            m = re.match(r'^(_Z\S+):', line)
+            if m:
+                cur = m.group(1) if pat.search(m.group(1)) else None
+                if cur:
+                    res[cur] = 0
+            elif cur and fused.match(line.strip()):
+                res[cur] += 1
+            elif line.startswith('.Lfunc_end'):
+                cur = None
+        return res
+    off, fast = counts_from_asm([]), counts_from_asm(['-ffp-contract=fast'])
+    assert len(off) >= 8 and set(off) == set(fast)
+    assert sum(fast.values()) > sum(off.values()), "contraction changes nothing in glue.hip: this check cannot see a leaked flag"
+    shipped = {k: sum(bool(fused.match(l.split()[0])) for l in v if l.split()) for k, v in _kernel_disassembly(tmp_path).items() if pat.search(k)}
+    assert shipped == off, "the shipped glue kernels are not the -ffp-contract=off build: %r vs %r" % (shipped, off)
+
+
 def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_path):
     """The miscompile of round 2 (profiles/r02_tuning_notes.md, "conv_wino"): when hipcc cannot prove a buffer load's scalar offset
     wave-uniform it wraps the load in a waterfall loop (v_readfirstlane ... s_and_saveexec ... s_cbranch_execnz), and one such build

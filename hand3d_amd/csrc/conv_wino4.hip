@@ -33,15 +33,9 @@
 #define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
 #endif
 
-#ifndef HP3D_W4_PAIRS
-#define HP3D_W4_PAIRS 1
-#endif
 #ifndef HP3D_W4_TIMING
 #define HP3D_W4_TIMING 0         // 1: diagnostic build -- every wave sums shader-clock intervals of its steps (planes 0..28 | window wait +
 #endif                           // transform | planes 30..35 | barrier | epilogue) into w4_timing[]; conv_wino4_launch prints them (profiles/r04_tuning_notes.md)
-#ifndef HP3D_W4_ORDER
-#define HP3D_W4_ORDER 1            // 1: XCD-affine item order (conv3_2 -6 %), 0: cout-block-major like conv_wino.hip
-#endif
 #define W4_WLOAD HP3D_BUFFER_LOAD8
 
 #if HP3D_W4_TIMING
@@ -63,39 +57,23 @@ constexpr int W4_SMEM_BYTES = 2 * W4_VBUF_FLOATS * 4 + 2 * 2 * W4_TILES * 4;    
 #endif
 constexpr int W4_RING = HP3D_W4_RING;              // weight fragments in flight (planes); must divide 36
 static_assert(W4_NP % W4_RING == 0, "static ring slots need a ring that divides the plane count");
-#ifndef HP3D_W4_ADEPTH
-#define HP3D_W4_ADEPTH 2
-#endif
-constexpr int W4_ADEPTH = HP3D_W4_ADEPTH;          // A fragments (planes) in flight from LDS: a plane is only 8 MFMAs = 256 cycles, and with one wave
+constexpr int W4_ADEPTH = 2;                       // A fragments (planes) in flight from LDS: a plane is only 8 MFMAs = 256 cycles, and with one wave
 static_assert(W4_NP % W4_ADEPTH == 0, "");         // per SIMD an LDS round trip that is not covered idles the matrix core
 constexpr int W4_HALF = 18;                        // planes reachable from one LDS base (16-bit immediate offsets)
 constexpr int W4_AGPR_PLANES = 32;                 // planes whose accumulators live in AGPRs (32 x 8 = 256); the rest in arch VGPRs
-#ifndef HP3D_W4_WPP
-#define HP3D_W4_WPP 2
-#endif
-constexpr int W4_WPP = HP3D_W4_WPP;                // window loads per plane: the 36 loads of the next step's window are SPREAD over the first
+constexpr int W4_WPP = 2;                          // window loads per plane: the 36 loads of the next step's window are SPREAD over the first
                                                    // 36 / W4_WPP planes.  Loads return in issue order, so a weight fragment issued behind a burst of
                                                    // 36 x 4 waves window loads waits for the whole burst to pass the CU's one address unit
                                                    // (measured: the wave stalled at plane 9 of every step, 25 % of the kernel's time)
-#ifndef HP3D_W4_TAT
-#define HP3D_W4_TAT 29
-#endif
-constexpr int W4_TRANSFORM_AT = HP3D_W4_TAT;       // the plane under which the next step's windows are transformed
+constexpr int W4_TRANSFORM_AT = 29;               // the plane under which the next step's windows are transformed
 
 // ISSUE ORDER of the 36 window loads of a step.  Window element (r, c) of every tile is the pixel (4 ty + r - 1, 4 tx + c - 1): the elements
 // (r, c), (r + 4, c), (r, c + 4), (r + 4, c + 4) of neighbouring tiles are the SAME pixels (the 6x6 windows overlap by two), i.e. the same
 // cache lines asked for by other lanes.  Issued in row-major order those requests lie up to 12 planes (3000 cycles) apart and the 32 KB L1,
 // through which ~300 KB stream per step, has dropped the line in between: every window line is filled up to four times.  Issued CLASS BY
 // CLASS ((r mod 4, c mod 4): 16 classes of 4 / 2 / 1 elements) the repeats follow within a plane or two and hit the line (or its pending
-// fill).  HP3D_W4_ISSUE=0: row-major (round 3).
-#ifndef HP3D_W4_ISSUE
-#define HP3D_W4_ISSUE 1
-#endif
-#if HP3D_W4_ISSUE
+// fill).  (Row-major, round 3's order: 2266 against 2326 images/s.)
 #define W4_ISSUE_ELEM(k) ((int[36]){0, 4, 24, 28, 1, 5, 25, 29, 2, 26, 3, 27, 6, 10, 30, 34, 7, 11, 31, 35, 8, 32, 9, 33, 12, 16, 13, 17, 14, 15, 18, 22, 19, 23, 20, 21}[(k)])
-#else
-#define W4_ISSUE_ELEM(k) (k)
-#endif
 
 // same quad swizzle as conv_wino2.hip (the V row of a tile is 16 channels = four 16-byte quads)
 __device__ __forceinline__ int w4_swz(int t) { return (0x78 >> (((t >> 2) & 3) * 2)) & 3; }
@@ -114,19 +92,9 @@ __device__ __forceinline__ void w4_bt_t(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5
     x4 = d42 - 2.f * d31;
     x5 = t5;
 }
-#ifndef HP3D_W4_SCALAR
-#define HP3D_W4_SCALAR 0           // 1: the input transform on scalar float ops (build with -fno-slp-vectorize): MI355X_MICROARCH.md prices packed f32
-#endif                             //    VALU beside MFMAs higher than two scalar ops; measured here, see profiles/r04_tuning_notes.md
+// (packed FMAs: scalar float transforms were re-measured on the final kernel in round 4, 2.3 % slower)
 __device__ __forceinline__ void w4_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
-#if HP3D_W4_SCALAR
-    float a0 = x0[0], a1 = x1[0], a2 = x2[0], a3 = x3[0], a4 = x4[0], a5 = x5[0];
-    float b0 = x0[1], b1 = x1[1], b2 = x2[1], b3 = x3[1], b4 = x4[1], b5 = x5[1];
-    w4_bt_t<float>(a0, a1, a2, a3, a4, a5);
-    w4_bt_t<float>(b0, b1, b2, b3, b4, b5);
-    x0 = f32x2{a0, b0}; x1 = f32x2{a1, b1}; x2 = f32x2{a2, b2}; x3 = f32x2{a3, b3}; x4 = f32x2{a4, b4}; x5 = f32x2{a5, b5};
-#else
     w4_bt_t<f32x2>(x0, x1, x2, x3, x4, x5);
-#endif
 }
 // A^T of F(4x4,3x3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
 __device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
@@ -155,7 +123,6 @@ struct W4Geom {
     }
     // item index (within one channel split) -> (cout block, tile block)
     __device__ __forceinline__ void item_decode(int r, int& cy_, int& tb_) const {
-#if HP3D_W4_ORDER
         // XCD-affine order: workgroup ids go round-robin over the 8 XCDs; within an XCD consecutive items are the cout blocks of ONE
         // tile block, so its windows are fetched from the fabric once per XCD and re-read from that XCD's L2
         // (round 4: any tile-block count -- the whole groups of eight tile blocks in that order, the up to seven left over behind them, still
@@ -171,10 +138,6 @@ struct W4Geom {
             cy_ = q - tbi * ncy;
             tb_ = (tile_blocks & ~7) + tbi;
         }
-        return;
-#endif
-        cy_ = r / tile_blocks;
-        tb_ = r - cy_ * tile_blocks;
     }
 };
 constexpr int W4_PIECE_FLOATS = W4_TILES * 16 * W4_COUTS;       // raw 4x4 outputs of one item: [tile 32][pixel 16][cout 64] = 128 KB
@@ -413,7 +376,7 @@ void conv_wino4_kernel(const ConvParams p) {
             // 7x7 filters keep the block form: their skip test would run four times per plane (measured 2-3 % slower).
 #pragma unroll
             for (int pl = 0; pl < W4_NP; ++pl) {
-                if (HP3D_W4_PAIRS && NSUB == 1) {
+                if (NSUB == 1) {
                     const int skip = (NSUB == 9 && !FIRST) ? ((pl / 6 == 5 && pl % 6 == 5) ? skip_ab : pl / 6 == 5 ? skip_a : pl % 6 == 5 ? skip_b : 0) : 0;
                     const int as = pl % W4_ADEPTH, bs = pl % W4_RING;
     #pragma unroll

@@ -1,4 +1,4 @@
-// conv_wino4.hip -- Winograd F(4x4, 3x3) on the f32 matrix cores (round 3).
+// conv_wino4.hip -- Winograd F(4x4, 3x3) on the f32 matrix cores (round 3; plane loop, window issue order, tail pieces: round 4).
 //
 // Same call sites as conv_wino.hip / conv_wino2.hip (NetworkOps.conv_relu + max_pool, utils/general.py:36-65; the 3x3 /
 // stride-1 layers and the 7x7 layers of PoseNet2D, nets/ColorHandPose3DNetwork.py:170-219, as nine 3x3 blocks), with the
@@ -19,11 +19,17 @@
 //   * V = B^T d B double buffered in LDS: 2 x 36 planes x 32 tiles x 16 channels = 147 KB;
 //   * loader thread = (tile, channel pair): 36 window loads of 8 bytes; the offsets are 6 row + 6 column terms (a row /
 //     column outside the image carries a constant that pushes the sum out of the buffer's range: reads as 0) added at
-//     issue time, not 36 registers; the loads are spread two per plane over the first 18 planes of a step;
+//     issue time, not 36 registers; the loads are spread two per plane over the first 18 planes of a step, in CLASS order: the
+//     elements (r, c), (r + 4, c), (r, c + 4), (r + 4, c + 4) -- the same pixels seen from neighbouring tiles -- follow each other, so
+//     the repeats hit the L1 line or its pending fill (round 4: +2.7 %);
+//   * a 3x3 plane is FOUR statements of two MFMAs with one of the plane's memory instructions behind each (next plane's A fragments |
+//     window | window | weight fragment): each issues under 64 matrix-core cycles instead of all at the plane boundary (round 4: +1.6 %;
+//     where the time goes was measured with -DHP3D_W4_TIMING=1, profiles/r04_sq_counters.md);
 //   * weights [36 planes][step][Cout/16][q][n][e] through a ring of 9 planes; work items in XCD-affine order (the cout blocks of a
 //     tile block run on one XCD, so its windows cross the fabric once per XCD);
 //   * a tile is 16 output pixels: the fused 2x2 max-pool takes four maxima per tile; ragged image edges (Ho, Wo not a
-//     multiple of 4) drop rows / columns through out-of-range store offsets.
+//     multiple of 4) drop rows / columns through out-of-range store offsets (no edge selects at all when Ho, Wo are multiples of 4);
+//   * a last round of items that is not full is cut into equal runs of item-steps, one per CU (TAIL, below).
 #include "hp3d_common.h"
 #include <cstdlib>
 #include <cstring>

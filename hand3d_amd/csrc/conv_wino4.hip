@@ -243,27 +243,29 @@ void conv_wino4_kernel(const ConvParams p) {
         for (int e = 0; e < 36; ++e) d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), soff);
     };
     float* const Vw = V + lt * W4_CK + ((lp >> 1) ^ w4_swz(lt)) * 4 + (lp & 1) * 2;      // this thread's slot in plane 0 of buffer 0
-    auto transform_commit = [&](int buf) {
-        // B^T d B in place: along the window rows first (plane row a), then along the columns (plane column b) straight into LDS
+    // B^T d B in place: along the window rows first (plane row a), then along the columns (plane column b); afterwards d[a * 6 + b] is this
+    // thread's value of plane a * 6 + b
+    auto transform_arith = [&]() {
 #pragma unroll
         for (int c = 0; c < 6; ++c)
             if (!(HP3D_W4_ABL & 32)) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
-        float* Vq0 = Vw + buf * W4_VBUF_FLOATS;
-        float* Vq1 = Vq0 + W4_HALF * W4_PLANE_FLOATS;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
+        for (int a = 0; a < 6; ++a)
             if (!(HP3D_W4_ABL & 32)) w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
-#pragma unroll
-            for (int b = 0; b < 6; ++b) {
-                const int pl = a * 6 + b;
-                float* dst = pl < W4_HALF ? Vq0 + pl * W4_PLANE_FLOATS : Vq1 + (pl - W4_HALF) * W4_PLANE_FLOATS;
+    };
+    auto v_write = [&](int buf, int pl) {
+        float* Vq0 = Vw + buf * W4_VBUF_FLOATS;
+        float* dst = pl < W4_HALF ? Vq0 + pl * W4_PLANE_FLOATS : Vq0 + W4_HALF * W4_PLANE_FLOATS + (pl - W4_HALF) * W4_PLANE_FLOATS;
 #if HP3D_W4_ABL & 64
-                asm volatile("" :: "v"(d[pl]));
+        asm volatile("" :: "v"(d[pl]));
 #else
-                *(f32x2*)dst = d[pl];
+        *(f32x2*)dst = d[pl];
 #endif
-            }
-        }
+    };
+    auto transform_commit = [&](int buf) {
+        transform_arith();
+#pragma unroll
+        for (int pl = 0; pl < W4_NP; ++pl) v_write(buf, pl);
     };
 
     // ---- MFMA role -------------------------------------------------------------------------------------------------------
@@ -407,6 +409,16 @@ void conv_wino4_kernel(const ConvParams p) {
                             if (HP3D_W4_ABL & 8) {}
                             else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
                             else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
+                        } else if (pl > W4_TRANSFORM_AT) {
+                            // V of the next step: the 36 values this thread transformed under plane 29 go to LDS three behind each of the two
+                            // middle pairs of planes 30..35 (as one burst under plane 29 the four waves queued 74 KB on the LDS port at once and
+                            // each sat ~900 cycles in front of its next MFMA: timing ablations, round-4 log section 5)
+                            if (!(HP3D_W4_ABL & 1)) {
+                                constexpr int PER = 36 / (2 * (W4_NP - 1 - W4_TRANSFORM_AT));
+                                static_assert(PER * 2 * (W4_NP - 1 - W4_TRANSFORM_AT) == 36, "");
+#pragma unroll
+                                for (int j = 0; j < PER; ++j) v_write(cur ^ 1, ((pl - W4_TRANSFORM_AT - 1) * 2 + (e - 1)) * PER + j);
+                            }
                         } else if (!(HP3D_W4_ABL & 2)) {
                             static_assert(W4_WPP % 2 == 0, "the plane's window loads go behind its two middle pairs, half each");
 #pragma unroll
@@ -454,7 +466,7 @@ void conv_wino4_kernel(const ConvParams p) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W4_TRANSFORM_AT + 1 - 36 / W4_WPP) : "memory");
                     { const unsigned long long t = W4_CLOCK(); tsum[5] += t - t_mark; t_mark = t; }
 #endif
-                    transform_commit(cur ^ 1);
+                    if (NSUB == 1) transform_arith(); else transform_commit(cur ^ 1);
 #if HP3D_W4_TIMING
                     { const unsigned long long t = W4_CLOCK(); tsum[1] += t - t_mark; t_mark = t; }
 #endif

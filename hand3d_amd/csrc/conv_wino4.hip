@@ -458,6 +458,10 @@ void conv_wino4_kernel(const ConvParams p) {
                             d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
                         }
                     }
+                    if (!(HP3D_W4_ABL & 1) && pl > W4_TRANSFORM_AT) {          // V of the next step, six values per plane (see the pair form)
+    #pragma unroll
+                        for (int j = 0; j < 36 / (W4_NP - 1 - W4_TRANSFORM_AT); ++j) v_write(cur ^ 1, (pl - W4_TRANSFORM_AT - 1) * (36 / (W4_NP - 1 - W4_TRANSFORM_AT)) + j);
+                    }
                 }
                 if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) {
 #if HP3D_W4_TIMING
@@ -466,7 +470,7 @@ void conv_wino4_kernel(const ConvParams p) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W4_TRANSFORM_AT + 1 - 36 / W4_WPP) : "memory");
                     { const unsigned long long t = W4_CLOCK(); tsum[5] += t - t_mark; t_mark = t; }
 #endif
-                    if (NSUB == 1) transform_arith(); else transform_commit(cur ^ 1);
+                    transform_arith();
 #if HP3D_W4_TIMING
                     { const unsigned long long t = W4_CLOCK(); tsum[1] += t - t_mark; t_mark = t; }
 #endif

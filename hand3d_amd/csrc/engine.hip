@@ -1613,6 +1613,9 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
     // staging: the packed blob is assembled on the host and uploaded once.  (The CPU interpreter's "device" memory IS host memory: it
     // packs straight into the blob -- copying 1.3 GB once more costs tens of seconds in the sandboxes the CPU suite runs in.)
 #ifdef HP3D_EMU
+    // (in place is safe against the one failure below, "incomplete variable set": variables can only be ADDED to a context, so every network
+    //  that was complete before this call is complete now, and all packing is done before that check -- the blob then holds every complete
+    //  network repacked in full, which is what ctx->nets still says)
     if (!ctx->blob) CHK(dev_realloc(ctx, &ctx->blob, ctx->T.blob_floats));
     memset(ctx->blob, 0, sizeof(float) * ctx->T.blob_floats);
     struct { float* p; float* data() { return p; } float& operator[](size_t i) { return p[i]; } } host{ctx->blob};

@@ -32,7 +32,7 @@
 #include "hp3d_common.h"
 #include <cstdlib>
 #ifndef HP3D_WINO_ABL
-#define HP3D_WINO_ABL 0          // timing ablations (scripts/gpu_abl.sh); any non-zero value computes wrong results
+#define HP3D_WINO_ABL 0          // timing ablations (scripts/history/gpu_abl.sh); any non-zero value computes wrong results
 #endif
 #include <cstring>
 #include <type_traits>

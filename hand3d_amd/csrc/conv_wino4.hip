@@ -36,7 +36,7 @@
 #include <type_traits>
 
 #ifndef HP3D_W4_ABL
-#define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_w4abl.sh); any non-zero value computes wrong results
+#define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_ab.sh with build_variant.sh -DHP3D_W4_ABL=n); any non-zero value computes wrong results
 #endif
 
 #ifndef HP3D_W4_TIMING

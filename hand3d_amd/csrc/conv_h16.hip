@@ -60,12 +60,26 @@ constexpr int h16_ring(int nt) { return nt == 4 ? HP3D_H16_RING : nt == 2 ? HP3D
 // patch pixels, K = 27 + two bias rows in two v_mfma_f32_32x32x16_f16 steps with the operand order, rounding points and
 // accumulation order of conv_first_kernel<true> (bit-identical halves), leaky-ReLU, zero outside the image (conv1_2's
 // SAME padding pads conv1_1's OUTPUT) -- so that conv1_1's 64-channel activation (5 GB at 128 x 480 x 640) never goes to HBM.
-template <int NT, bool POOL, int WPS, bool FUSE = false>
+// KS (round 4): the filter size -- 3 (the trunk layers), 7 (PoseNet2D's score-map stages, nets/ColorHandPose3DNetwork.py:206-215) or 1 (the
+// 1x1 layers in front of the score-map heads, :160, :203, :213).  Only the patch extent (16 + KS - 1)^2, its halo and the number of taps
+// change; 7x7 / 1x1 run the single-buffer form (NT <= 2), the conflict-free lane map of the A fragments is the 3x3 one (18-pixel rows).
+template <int NT, bool POOL, int WPS, bool FUSE = false, int KS = 3>
 HP3D_KERNEL2(256, WPS)
 void conv_h16_kernel(const ConvParams p) {
-    constexpr bool DB = WPS == 1;
+    constexpr bool DB = WPS == 1 && KS == 3;
     constexpr int HRING = h16_ring(NT);
-    static_assert(!FUSE || (NT == 1 && POOL && !DB), "fused first block: 64 -> 64 couts, pooled, single patch buffer");
+    static_assert(!FUSE || (NT == 1 && POOL && !DB && KS == 3), "fused first block: 64 -> 64 couts, pooled, single patch buffer");
+    static_assert(KS == 1 || KS == 3 || KS == 7, "");
+    static_assert(KS == 3 || (!POOL && NT <= 2), "7x7 / 1x1: plain epilogue, single patch buffer");
+    // patch geometry of this filter size (the names shadow the 3x3 constants above on purpose)
+    constexpr int HPW = HT + KS - 1;                         // patch width / height
+    constexpr int HPATCH_FLOATS = HPW * HPW * HPITCH;
+    constexpr int HPIECES = HPW * HPW * 8;
+    constexpr int HPVEC = (HPIECES + 255) / 256;             // 16-byte pieces per thread: 8 (1x1), 11 (3x3), 16 (7x7)
+    constexpr int HPG = (HPVEC + HPGS - 1) / HPGS;
+    constexpr int NSTEP = 4 * KS * KS;                       // K-steps of a 64-half chunk: 4 per tap
+    constexpr int HPSTEP = NSTEP / HPG;
+    constexpr int PAD = (KS - 1) / 2;
     HP3D_DYN_SMEM(smem);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
@@ -89,7 +103,8 @@ void conv_h16_kernel(const ConvParams p) {
     // cycles per read instead of 4).  Tap and K-step offsets shift all lanes alike and keep the property.
     const int pdy = li >> 4;
     const int pj = li & 15;
-    const int pdx = pdy == 0 ? (pj < 4 ? pj : pj < 12 ? pj + 4 : pj - 8)
+    const int pdx = KS != 3 ? pj
+                  : pdy == 0 ? (pj < 4 ? pj : pj < 12 ? pj + 4 : pj - 8)
                              : (pj < 2 ? pj + 14 : pj < 4 ? pj - 2 : pj < 12 ? pj + 2 : pj - 10);
     int abase[4];
 #pragma unroll
@@ -130,7 +145,7 @@ void conv_h16_kernel(const ConvParams p) {
         }
     }
     const int wbase = (tid >> 3) * HPITCH + (tid & 7) * 4;     // LDS float index of this thread's patch piece 0 (piece v: + 32 v pixels)
-    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(9 * p.Cin) * (unsigned)p.Cout * 4u);
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(KS * KS * p.Cin) * (unsigned)p.Cout * 4u);
     const int tap_stride_b = KB * CO32 * 1024;           // bytes between taps of the packed weights
 
     for (int item = blockIdx.x; item < nitems; item += (int)gridDim.x) {
@@ -152,7 +167,7 @@ void conv_h16_kernel(const ConvParams p) {
             const int idx = tid + v * 256;
             const int pix = idx >> 3, c4 = idx & 7;
             const int py = pix / HPW, px = pix - py * HPW;
-            const int gy = oy0 - 1 + py, gx = ox0 - 1 + px;
+            const int gy = oy0 - PAD + py, gx = ox0 - PAD + px;
             const bool ok = idx < HPIECES && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
             poff[v] = ok ? ((gy * p.W + gx) * p.in_cs + c4 * 4) * 4 : OOR;
         }
@@ -196,14 +211,21 @@ void conv_h16_kernel(const ConvParams p) {
         // a whole chunk into buffer 0 with all pieces in flight at once (the fragment registers are free at that point), and
         // the first RING-1 K-steps of its weights: (tap, ks) = (s / 4, s % 4)
         auto load_chunk = [&](int chunk) {
-            f32x4 first[HPVEC];
+            constexpr int GRP = HPVEC <= 11 ? HPVEC : 8;          // pieces in flight at once (7x7: 16 pieces in two rounds: registers)
 #pragma unroll
-            for (int v = 0; v < HPVEC; ++v) first[v] = HP3D_BUFFER_LOAD16(irsrc, poff[v], chunk * 128);
+            for (int v0 = 0; v0 < HPVEC; v0 += GRP) {
+                f32x4 first[GRP];
 #pragma unroll
-            for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, chunk * 4 + (s & 3));
+                for (int v = 0; v < GRP; ++v)
+                    if (v0 + v < HPVEC) first[v] = HP3D_BUFFER_LOAD16(irsrc, poff[v0 + v], chunk * 128);
+                if (v0 == 0) {
 #pragma unroll
-            for (int v = 0; v < HPVEC; ++v)
-                if (tid + v * 256 < HPIECES) *(f32x4*)(smem + wbase + v * (32 * HPITCH)) = first[v];
+                    for (int s = 0; s < HRING - 1; ++s) b_fetch(s, s >> 2, chunk * 4 + (s & 3));
+                }
+#pragma unroll
+                for (int v = 0; v < GRP; ++v)
+                    if (v0 + v < HPVEC && tid + (v0 + v) * 256 < HPIECES) *(f32x4*)(smem + wbase + (v0 + v) * (32 * HPITCH)) = first[v];
+            }
         };
         // fused first block: the patch = conv1_1 over the image.  The 20 x 20 x 3 float32 image window (zero outside the image)
         // is staged in LDS behind the patch buffer, followed by the constants 1.0 (bias rows) and 0.0 (K tail); then, row block by
@@ -269,9 +291,9 @@ void conv_h16_kernel(const ConvParams p) {
             const bool has_next = DB && chunk + 1 < nchunks;
             if (!DB && chunk > 0) { __syncthreads(); load_chunk(chunk); __syncthreads(); }
             a_fetch(0, cur, 0, 0);
-            // 36 K-steps of this chunk, straight line: step s = 4 tap + ks
+            // the 4 KS^2 K-steps of this chunk (36 for 3x3), straight line: step s = 4 tap + ks
 #pragma unroll
-            for (int s = 0; s < 36; ++s) {
+            for (int s = 0; s < NSTEP; ++s) {
                 const int tap = s >> 2, ks = s & 3;
                 HP3D_SCHED_BARRIER();
                 // next chunk's patch, group g: fetched at step g HPSTEP, committed to the other buffer HPSTEP - 1 steps later
@@ -280,15 +302,15 @@ void conv_h16_kernel(const ConvParams p) {
                     if (s % HPSTEP == HPSTEP - 1) patch_commit(cur ^ 1, s / HPSTEP);
                 }
                 // prefetch: A fragments of step s+1 (other register set), weight fragments of step s + RING - 1
-                if (s + 1 < 36 && !(HP3D_H16_ABL & 8)) {
-                    const int t1 = (s + 1) >> 2, r1 = t1 / 3, c1 = t1 - r1 * 3;
+                if (s + 1 < NSTEP && !(HP3D_H16_ABL & 8)) {
+                    const int t1 = (s + 1) >> 2, r1 = t1 / KS, c1 = t1 - r1 * KS;
                     a_fetch((s + 1) & 1, cur, (r1 * HPW + c1) * HPITCH * 4, (s + 1) & 3);
                 }
                 {
                     const int s2 = s + HRING - 1;
                     if (HP3D_H16_ABL & 4) { asm volatile("" : "+v"(fb[s2 % HRING][0])); }
-                    else if (s2 < 36) b_fetch(s2 % HRING, s2 >> 2, chunk * 4 + (s2 & 3));
-                    else if (has_next) b_fetch(s2 % HRING, (s2 - 36) >> 2, (chunk + 1) * 4 + ((s2 - 36) & 3));
+                    else if (s2 < NSTEP) b_fetch(s2 % HRING, s2 >> 2, chunk * 4 + (s2 & 3));
+                    else if (has_next) b_fetch(s2 % HRING, (s2 - NSTEP) >> 2, (chunk + 1) * 4 + ((s2 - NSTEP) & 3));
                 }
                 HP3D_SCHED_BARRIER();          // the prefetches are issued BEFORE this step's MFMAs: a whole step of latency cover
 #pragma unroll
@@ -394,13 +416,17 @@ void conv_h16_kernel(const ConvParams p) {
     }
 }
 
-template <int NT, bool POOL>
+template <int NT, bool POOL, int KS = 3>
 void h16_launch_t(const ConvParams& p, hipStream_t s) {
     static bool attr_done[64] = {};
-    constexpr int WPS = NT == 4 ? 1 : NT == 2 ? 2 : 3;
-    auto k = conv_h16_kernel<NT, POOL, WPS>;
     constexpr int SLABS = 4 * 4 * 32 * (64 * NT + 16);                       // epilogue: 4 waves x 4 row blocks x 32 pixels
-    constexpr int PATCHES = (WPS == 1 ? 2 : 1) * HPATCH_FLOATS * 4;
+    constexpr int PATCH1 = (HT + KS - 1) * (HT + KS - 1) * HPITCH * 4;       // one patch buffer of this filter size
+    constexpr int WPS0 = NT == 4 ? 1 : NT == 2 ? 2 : 3;
+    constexpr int SMEM0 = ((WPS0 == 1 ? 2 : 1) * PATCH1) > SLABS ? ((WPS0 == 1 ? 2 : 1) * PATCH1) : SLABS;
+    constexpr int WPS = SMEM0 * WPS0 <= 160 * 1024 ? WPS0 : WPS0 - 1;         // (7x7, one cout block per wave: two workgroups of 70 KB, not three)
+    static_assert(WPS >= 1 && (WPS > 1 || KS == 3), "");
+    auto k = conv_h16_kernel<NT, POOL, WPS, false, KS>;
+    constexpr int PATCHES = (WPS == 1 ? 2 : 1) * PATCH1;
     constexpr int SMEM = PATCHES > SLABS ? PATCHES : SLABS;
     static_assert(SMEM * WPS <= 160 * 1024, "LDS per CU");
     if (hp3d_first_use_on_device(attr_done))
@@ -451,15 +477,25 @@ int conv_h16_fused12_launch(const ConvParams& p, hipStream_t s) {
 // Returns the per-wave cout blocks NT (1, 2 or 4) or 0.  mode 1: only when the grid fills the chip; mode 2 (tests): whenever
 // the shape allows
 int conv_h16_eligible(int mode, int k, int stride, int cin_units, int Cout, int Ho, int Wo, int B, int out_f32, int out_cs) {
-    if (!mode || k != 3 || stride != 1 || out_f32 || cin_units % 32 || cin_units < 32 || Cout % 64 || out_cs % 8) return 0;
-    const int nt = h16_nt(Cout, cin_units);
+    if (!mode || (k != 3 && k != 7 && k != 1) || stride != 1 || out_f32 || cin_units % 32 || cin_units < 32 || Cout % 64 || out_cs % 8) return 0;
+    int nt = h16_nt(Cout, cin_units);
+    if (k != 3 && nt == 4) nt = 2;                      // 7x7 / 1x1: the single-buffer forms only
     const long items = (long)B * ((Ho + HT - 1) / HT) * ((Wo + HT - 1) / HT) * (Cout / (64 * nt));
     return (mode == 2 || items >= 256) ? nt : 0;
 }
 
 int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s) {
-    const int nt = p.Cout % 64 == 0 ? h16_nt(p.Cout, p.Cin) : 0;
+    int nt = p.Cout % 64 == 0 ? h16_nt(p.Cout, p.Cin) : 0;
     if (!nt || (pool && ((p.Ho | p.Wo) & 1))) return -1;
+    const int k = 2 * p.pad_t + 1;                      // SAME padding, stride 1: the filter size
+    if (k == 7 || k == 1) {
+        if (pool) return -1;
+        if (nt == 4) nt = 2;
+        if (k == 7) { if (nt == 2) h16_launch_t<2, false, 7>(p, s); else h16_launch_t<1, false, 7>(p, s); }
+        else { if (nt == 2) h16_launch_t<2, false, 1>(p, s); else h16_launch_t<1, false, 1>(p, s); }
+        return 0;
+    }
+    if (k != 3) return -1;
     if (nt == 4) { if (pool) h16_launch_t<4, true>(p, s); else h16_launch_t<4, false>(p, s); }
     else if (nt == 2) { if (pool) h16_launch_t<2, true>(p, s); else h16_launch_t<2, false>(p, s); }
     else { if (pool) h16_launch_t<1, true>(p, s); else h16_launch_t<1, false>(p, s); }

@@ -271,6 +271,7 @@ struct hp3d_ctx {
     bool shared_weights = false;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int use_h16 = 1;           // half-precision 3x3 trunk layers on conv_h16.hip (option "f16_impl" = "h16" | "mfma")
+    int h16_k7k1 = 1;          // ... and the 7x7 / 1x1 layers with >= 64 couts on its single-buffer forms (option "f16_k7k1" = 0 | 1)
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
     int use_lift_fused = -1;   // the lifting stage as one launch (lift_fused.hip): -1 auto (B <= 4), 0 never, 1 always (option "lift_fused")
     unsigned* d_liftbar = nullptr;
@@ -667,7 +668,8 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = f16; p.out_f32 = 0; p.nsub = 1;
         ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
         conv_first_launch(p, ctx->stream);
-    } else if (f16 && ctx->use_h16 && l.mode == 0 && !ctx->conv_naive &&
+    } else if (f16 && ctx->use_h16 && !ctx->conv_naive &&
+               ((l.mode == 0 && l.k == 3) || (ctx->h16_k7k1 && ((l.k == 7 && (l.mode == 0 || l.mode == 2)) || (l.k == 1 && l.mode == 0)))) &&
                conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32, out_cs) &&
                ((uintptr_t)out & 15) == 0 && !(pool && ((Ho | Wo) & 1))) {
         ConvParams p;
@@ -677,7 +679,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
         p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 1; p.out_f32 = 0; p.nsub = 1;
-        ProfScope ps(ctx, l.name, pool ? "conv_h16_3x3_pool" : "conv_h16_3x3", flops, bytes);
+        ProfScope ps(ctx, l.name, l.k == 7 ? "conv_h16_7x7" : l.k == 1 ? "conv_h16_1x1" : pool ? "conv_h16_3x3_pool" : "conv_h16_3x3", flops, bytes);
         ++ctx->conv_h16_launches;
         if (conv_h16_launch(p, pool, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 launch failed for %s", l.name.c_str());
     } else if (ctx->conv_naive && l.mode == 0 && !pool && !f16) {
@@ -1159,7 +1161,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1527,6 +1529,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "f16_k7k1" && (v == "0" || v == "1")) { ctx->h16_k7k1 = v == "1"; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
     if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
     if (k == "conv_impl" && (v == "mfma" || v == "naive" || v == "direct" || v == "winograd")) {

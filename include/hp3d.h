@@ -109,6 +109,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            the 3x3 / stride-1 layers with Cin >= 64 run on the half-precision trunk kernel (conv_h16.hip)
  *                            whenever their grid fills the chip | never (general kernel only) | whenever the shape allows
  *                            (tests).  Same MFMA and packed weights either way: results agree to accumulation order;
+ *          "f16_k7k1"     = "1" (default) | "0": with "f16_impl" on conv_h16.hip, PoseNet2D's 7x7 score-map stages and the 1x1 layers with
+ *                            >= 64 couts also run on it (single-buffer forms, patch of (16 + k - 1)^2 pixels) | on the general kernel.
+ *                            Same MFMA and packed weights: results agree to accumulation order;
  *          "f16_fuse12"   = "1" (default) | "0": with half-precision trunks and the layer on conv_h16.hip, conv1_1 is computed
  *                            inside conv1_2's patch stage (one launch for conv1_1 + conv1_2 + max-pool; conv1_1's activation
  *                            never reaches HBM).  Bit-identical to the two-launch form;

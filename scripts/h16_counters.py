@@ -49,7 +49,7 @@ def main():
              '`bash scripts/gpu_pmc_h16.sh` (rocprofv3 --kernel-trace --pmc, one pass per counter pair; bench.py --dtype f16 --batch 32',
              '--height 480 --width 640 --option streams=1), summarised by `scripts/h16_counters.py`; launches longer than 100 us,',
              'duration-weighted.  clock = SQ_BUSY_CYCLES / 32 SEs / duration; MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x cycles).', '',
-             '| instantiation <cout blocks per wave, pool, workgroups per CU> | launches | launch us | clock GHz | MFMA busy | busy x clock / 2.4 GHz | L2 hit rate |',
+             '| instantiation <cout blocks per wave, pool, workgroups per CU, fused first block, filter size> | launches | launch us | clock GHz | MFMA busy | busy x clock / 2.4 GHz | L2 hit rate |',
              '|---|---|---|---|---|---|---|']
     for k, v in sorted(agg.items()):
         w = sum(x[0] for x in v)

@@ -246,6 +246,39 @@ def test_f16_trunks_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights)
         net.init_from_dict(synth_weights, dtype=0)
 
 
+def test_f16_7x7_and_1x1_layers_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights):
+    """conv_h16.hip's 7x7 / 1x1 forms (option f16_k7k1, round 4): PoseNet2D's score-map stages (Mconv1_stage2: 149 -> 128 over the concat
+    buffer, Mconv2..5: 128 -> 128, nets/ColorHandPose3DNetwork.py:206-215) and the 1x1 layers with >= 64 couts (conv6_1_CPM, Mconv6), on a
+    crop whose score maps are 17 x 3 (a second, ragged 16 x 16 tile below the first -- the GPU test has 2 x 2 tiles --, the 7x7 halo crossing both the image border and the tile border), vs the
+    same layers on the general f16 kernel (same MFMA, same packed weights: accumulation order only) and vs the oracle with the same
+    rounding points; the launch counter shows the layers really moved."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=emu_engine)
+    net.init_from_dict(synth_weights, dtype='f16')
+    try:
+        emu_engine.set_option('f16_impl', 'h16_force')
+        for (h, w) in ((136, 24),):
+            crop = synth.make_batch(11, 1, h, w)
+            emu_engine.set_option('f16_k7k1', '0')
+            n0 = emu_engine.counter('conv_h16_launches')
+            ref = net.inference_pose2d(crop)
+            n1 = emu_engine.counter('conv_h16_launches')
+            emu_engine.set_option('f16_k7k1', '1')
+            got = net.inference_pose2d(crop)
+            n2 = emu_engine.counter('conv_h16_launches')
+            # + conv6_1_CPM (1x1), 2 stages x (5 x 7x7 + Mconv6 1x1)
+            assert (n2 - n1) - (n1 - n0) == 1 + 2 * 6
+            orc = N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)
+            for a, b, c in zip(got, ref, orc):
+                assert a.shape == (1, h // 8, w // 8, 21)
+                assert np.abs(a - b).max() < 5e-4
+                assert np.abs(a - c).max() < 2e-3
+    finally:
+        emu_engine.set_option('f16_impl', 'h16')
+        emu_engine.set_option('f16_k7k1', '1')
+        net.init_from_dict(synth_weights, dtype=0)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 17, 21, 128, 256, 0), (2, 14, 20, 64, 128, 1),
                                   # 64-tile x 64-cout items (16-channel steps, swizzled V): conv1_2-like, odd sizes, 3 cout blocks
                                   (2, 16, 32, 64, 64, 1), (1, 17, 21, 32, 64, 0), (1, 12, 20, 96, 192, 0)],

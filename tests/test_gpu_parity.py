@@ -734,7 +734,8 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
             sms = net16.inference_pose2d(crop)
             n1 = gpu_engine.counter('conv_h16_launches')
             out[impl] = (small, sms)
-            assert (n1 - n0 == 0) if impl == 'mfma' else (n1 - n0 >= (13 + 9 if impl == 'h16_force' else 1)), (impl, n1 - n0)
+            # h16_force: 13 + 9 3x3 layers, and (round 4, option f16_k7k1) PoseNet2D's ten 7x7 stages + three 1x1 layers with >= 64 couts
+            assert (n1 - n0 == 0) if impl == 'mfma' else (n1 - n0 >= (13 + 9 + 13 if impl == 'h16_force' else 1)), (impl, n1 - n0)
             assert np.abs(small - rs16).max() < 2e-3
             for a, b in zip(sms, r16):
                 assert np.abs(a - b).max() < 2e-3
@@ -742,8 +743,18 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
             assert np.abs(out[impl][0] - out['mfma'][0]).max() < 5e-4
             for a, b in zip(out[impl][1], out['mfma'][1]):
                 assert np.abs(a - b).max() < 5e-4
-        # conv1_1 computed inside conv1_2's patch stage (default) == conv_first<F16> followed by conv_h16, bit for bit
+        # the 7x7 / 1x1 forms off: those 13 layers go back to the general kernel, same results to accumulation order
         gpu_engine.set_option('f16_impl', 'h16_force')
+        gpu_engine.set_option('f16_k7k1', '0')
+        n0 = gpu_engine.counter('conv_h16_launches')
+        sms_k3 = net16.inference_pose2d(crop)
+        n1 = gpu_engine.counter('conv_h16_launches')
+        gpu_engine.set_option('f16_k7k1', '1')
+        net16.inference_pose2d(crop)
+        assert (gpu_engine.counter('conv_h16_launches') - n1) - (n1 - n0) == 13
+        for a, b in zip(out['h16_force'][1], sms_k3):
+            assert np.abs(a - b).max() < 5e-4
+        # conv1_1 computed inside conv1_2's patch stage (default) == conv_first<F16> followed by conv_h16, bit for bit
         gpu_engine.set_option('f16_fuse12', '0')
         _, small_unfused = gpu_engine.handsegnet(img, want_small=True)
         sms_unfused = net16.inference_pose2d(crop)
@@ -753,6 +764,7 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
             assert np.array_equal(a, b)
     finally:
         gpu_engine.set_option('f16_fuse12', '1')
+        gpu_engine.set_option('f16_k7k1', '1')
         gpu_engine.set_option('f16_impl', 'h16')
         gpu_engine.load_weight_dict(synth_weights)
         gpu_engine.finalize_weights(0)

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhp3d.so')
-SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
+SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino4w.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
 HEADERS = ['hp3d_common.h', 'lift_fused.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
@@ -19,7 +19,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # a third fewer VALU instructions per step, and nothing in that file feeds a discontinuous decision (the later -ffp-contract wins)
 # (-pragma-unroll-threshold: its 36-plane step body is one straight-line block by design; past the default limit hipcc silently
 # stops unrolling and the 288 accumulators land in scratch)
-EXTRA_FLAGS = {'conv_wino4.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000']}
+EXTRA_FLAGS = {'conv_wino4.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000'],
+               'conv_wino4w.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000']}      # (the same kernel with wide items)
 
 
 def _stale(target, deps):

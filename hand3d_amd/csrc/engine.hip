@@ -286,6 +286,8 @@ struct hp3d_ctx {
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
     int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
+    int w4_wide = 0;           // conv_wino4w.hip: the wide-item form (16 tiles x 128 couts, 32-channel steps) for the 3x3 layers it takes (option "wino4_wide": 0 | 1 | 2 = force)
+    long conv_wino4w_launches = 0;
     long conv_wino4_tail_launches = 0;
     long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
@@ -578,6 +580,9 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live));
     if (take4 || take2) {
         if (take4) wino2_ks = wino4_ks;          // (the block below serves both kernels: same parameters, same split / reduce protocol)
+        // conv_wino4w.hip: the same arithmetic and packed filters with wide items, for the 3x3 layers with Cout % 128 == 0 that fill the chip unsplit
+        const bool wide = take4 && ctx->w4_wide && wino2_ks == 1 &&
+            conv_wino4w_eligible(ctx->w4_wide, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool);
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + (take4 ? l.ww4_off : l.ww2_off); p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -594,7 +599,8 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                 ctx->col_floats = need;
             }
             p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
-        } else if (take4 && l.k == 3 && ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+        } else if (take4 && l.k == 3 && ctx->w4_tail &&
+                   (wide ? conv_wino4w_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) : conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr)) > 0) {
             // an under-filled last round of items runs as channel slices, one piece per CU (conv_wino4.hip, TAIL): scratch for the raw sums
             const size_t need = conv_wino4_tail_floats();
             if (need > ctx->col_floats) {
@@ -607,14 +613,17 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         }
         {
             const char* kn = take4 ? (l.k == 7 ? (wino2_ks > 1 ? "conv_wino4_f4x4_3x3_as7x7_splitk" : "conv_wino4_f4x4_3x3_as7x7")
-                                               : wino2_ks > 1 ? "conv_wino4_f4x4_3x3_splitk" : pool ? "conv_wino4_f4x4_3x3_pool" : "conv_wino4_f4x4_3x3")
+                                               : wino2_ks > 1 ? "conv_wino4_f4x4_3x3_splitk"
+                                               : wide ? (pool ? "conv_wino4w_f4x4_3x3_pool" : "conv_wino4w_f4x4_3x3") : pool ? "conv_wino4_f4x4_3x3_pool" : "conv_wino4_f4x4_3x3")
                                     : (l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
                                                : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3");
             ProfScope ps(ctx, l.name, kn, flops, bytes);
-            if (take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream))
+            if (wide ? conv_wino4w_launch(p, pool, ctx->stream)
+                     : take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream))
                 HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", take4 ? "F(4x4,3x3)" : "2 workgroups per CU");
         }
         ++(take4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
+        if (wide) ++ctx->conv_wino4w_launches;
         if (wino2_ks > 1) {
             ProfScope ps(ctx, l.name, pool ? "conv_splitk_reduce_pool" : "conv_splitk_reduce", 0.0, 4.0 * (wino2_ks + 1) * B * Ho * Wo * l.cout_pad);
             if (pool)
@@ -1161,7 +1170,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->w4_wide = ctx->w4_wide; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1522,6 +1531,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "wino4_wide" && (v == "0" || v == "1" || v == "force")) { ctx->w4_wide = v == "0" ? 0 : v == "1" ? 1 : 2; ++ctx->graph_epoch; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
@@ -2013,17 +2023,21 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.act = act; p.im2col = 0; p.ksplit = op_ks2; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = k == 7 ? 9 : 1;
         float* d_part = nullptr;
+        const bool opw = op4 && ctx->w4_wide && op_ks2 == 1 && conv_wino4w_eligible(ctx->w4_wide, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool);
         if (op_ks2 > 1) {
             d_part = S.alloc<float>((size_t)op_ks2 * B * Ho * Wo * Cout); NN(ctx, d_part);
             p.out = d_part;
-        } else if (op4 && k == 3 && ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+        } else if (op4 && k == 3 && ctx->w4_tail &&
+                   (opw ? conv_wino4w_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) : conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr)) > 0) {
             p.partial = S.alloc<float>(conv_wino4_tail_floats()); NN(ctx, p.partial);         // tail pieces (conv_wino4.hip, TAIL)
             p.partial_cap = conv_wino4_tail_floats();
             ++ctx->conv_wino4_tail_launches;
         }
-        if (op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream))
+        if (opw ? conv_wino4w_launch(p, pool, ctx->stream)
+                : op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream))
             HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
         ++(op4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
+        if (opw) ++ctx->conv_wino4w_launches;
         if (op_ks2 > 1 && pool)
             conv_splitk_reduce_pool_launch(d_part, op_ks2, B, Ho, Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
         else if (op_ks2 > 1)
@@ -2227,6 +2241,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }
+    if (k == "conv_wino4w_launches") { *value = ctx->conv_wino4w_launches + (ctx->kid ? ctx->kid->conv_wino4w_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }

@@ -105,6 +105,17 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  "v_mfma_f32_16x16x4_f32 %1, %3, %4, 0"                                                              \
                  : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
                  : "v"(a0e), "v"(a1e), "v"(be))
+// conv_wino4w.hip's pair: ONE A fragment element (16 tiles), the B elements of the wave's two cout groups
+#define HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e)                                                            \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %1, %2, %4, %1"                                                             \
+                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
+                 : "v"(ae), "v"(b0e), "v"(b1e))
+#define HP3D_MFMA16_PAIRB_FIRST(REG, acc0, acc1, ae, b0e, b1e)                                                      \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, 0\n\t"                                                        \
+                 "v_mfma_f32_16x16x4_f32 %1, %2, %4, 0"                                                              \
+                 : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
+                 : "v"(ae), "v"(b0e), "v"(b1e))
 // the first step of an item: the accumulators start from the inline constant 0 (never skipped)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                                                         \
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, 0\n\t"                                                       \
@@ -291,6 +302,10 @@ int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, in
 int conv_wino4_launch(const ConvParams& p, int pool, hipStream_t s);
 // scratch (floats) the tail pieces of any conv_wino4 launch can need: two 32-tile x 64-cout blocks of raw 4x4 outputs per CU
 size_t conv_wino4_tail_floats();
+// conv_wino4w.hip: the same Winograd form with wide items (16 tiles x 128 couts, 32-channel steps); same packed filters and tail scratch
+int conv_wino4w_eligible(int mode /* 1: when the launch fills the chip, 2: whenever the shape allows */, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool);
+int conv_wino4w_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
+int conv_wino4w_launch(const ConvParams& p, int pool, hipStream_t s);
 // > 0: conv_wino4_launch would share the last round of this layer out as tail pieces (given the scratch); channel steps per workgroup
 int conv_wino4_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);

@@ -156,6 +156,17 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
         (acc0) = _z; (acc1) = _z;                                                     \
         HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, 0);                    \
     } while (0)
+#define HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e)                              \
+    do {                                                                              \
+        (acc0) = hp3d_emu_mfma_16x16x4((ae), (b0e), (acc0));                          \
+        (acc1) = hp3d_emu_mfma_16x16x4((ae), (b1e), (acc1));                          \
+    } while (0)
+#define HP3D_MFMA16_PAIRB_FIRST(REG, acc0, acc1, ae, b0e, b1e)                        \
+    do {                                                                              \
+        const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                        \
+        (acc0) = _z; (acc1) = _z;                                                     \
+        HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e);                             \
+    } while (0)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                      \
     do {                                                                          \
         const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                    \

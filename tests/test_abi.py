@@ -98,8 +98,9 @@ def test_fp_contraction_is_confined_to_the_winograd_f4x4_kernel(tmp_path):
     of them in the interpolation kernels -- i.e. the check would see a leaked flag."""
     from hand3d_amd import build as hb
     assert '-ffp-contract=off' in hb.FLAGS and not any('contract=fast' in f for f in hb.FLAGS)
-    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip'}, "a second file with its own floating-point flags: extend this test before adding it"
-    assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip']
+    # (conv_wino4w.hip is the same kernel with wide work items: same transforms, same reason)
+    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip', 'conv_wino4w.hip'}, "another file with its own floating-point flags: extend this test before adding it"
+    assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip'] and '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4w.hip']
     pat = re.compile(r'seg_upsample_softmax|seg_softmax|mask_grow|crop_and_resize|resize_bilinear|preprocess_u8|kp_detect|argmax2d')
     fused = re.compile(r'v_(fma|fmac|mad|pk_fma)_f32')
 

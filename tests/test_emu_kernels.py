@@ -112,6 +112,21 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     assert np.abs(small_4 - rs).max() < 3e-5
     for a, b in zip(sms_4, ref):
         assert np.abs(a - b).max() < 3e-5
+    # ... and the 3x3 layers with Cout % 128 == 0 onto conv_wino4w.hip (wide items) through the executor: the same packed filters,
+    # in-place activations with channel strides, pooled layers
+    emu_engine.set_option('wino4', '1')
+    emu_engine.set_option('wino4_wide', 'force')
+    try:
+        n0 = emu_engine.counter('conv_wino4w_launches')
+        _, small_w4 = emu_engine.handsegnet(img, want_small=True)
+        sms_w4 = net.inference_pose2d(crop)
+        assert emu_engine.counter('conv_wino4w_launches') >= n0 + 20
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino4_wide', '0')
+    assert np.abs(small_w4 - rs).max() < 3e-5
+    for a, b in zip(sms_w4, ref):
+        assert np.abs(a - b).max() < 3e-5
     rng = np.random.default_rng(5)
     sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
     hs = synth.hand_sides(2)
@@ -455,6 +470,43 @@ def test_winograd_f4x4_kernel_on_interpreter(emu_engine, case):
             assert np.abs(y - r).max() < 1e-4, (sk, np.abs(y - r).max())
     finally:
         emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+
+
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 8, 8, 64, 128, 1), (1, 7, 9, 128, 128, 0), (1, 8, 12, 96, 256, 1), (1, 17, 21, 32, 128, 0),
+                                  # 8 tile blocks of 16 (the XCD-affine order), a single 32-channel step per item, three cout blocks, a pooled layer with an odd pooled extent
+                                  (2, 32, 32, 32, 128, 0), (1, 20, 24, 64, 384, 0), (1, 18, 22, 32, 128, 1),
+                                  # tail pieces on the interpreter's 3 CUs: 4 items (one round + one), 5 (one round + two: a run crosses items), 2 (less than a round)
+                                  (1, 16, 16, 128, 512, 0), (1, 16, 16, 128, 512, 1), (5, 16, 16, 128, 128, 0), (5, 16, 16, 128, 128, 1), (2, 16, 16, 128, 128, 0)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_winograd_f4x4_wide_items_on_interpreter(emu_engine, case):
+    """conv_wino4w.hip (option wino4_wide = force, round 4): the F(4x4,3x3) kernel with items of 16 tiles x 128 couts in 32-channel steps --
+    loader thread = (tile, channel pair of 32), V rows of eight swizzled quads, two B fragments per k quad from the UNCHANGED packed
+    filters (16-channel steps 2 s + h), eight MFMA pairs per plane, epilogue over two cout groups, tail pieces with this item shape.
+    Against the float64 oracle, and against conv_wino4.hip on the same input: the same products, another summation order."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case) + 23)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('wino4', '1')
+    emu_engine.set_option('wino_splitk', '0')
+    try:
+        outs = {}
+        for wide in ('force', '0'):
+            emu_engine.set_option('wino4_wide', wide)
+            n0, w0 = emu_engine.counter('conv_wino4_launches'), emu_engine.counter('conv_wino4w_launches')
+            outs[wide] = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+            assert emu_engine.counter('conv_wino4_launches') == n0 + 1
+            assert emu_engine.counter('conv_wino4w_launches') == w0 + (1 if wide == 'force' else 0)
+            assert outs[wide].shape == r.shape and np.abs(outs[wide] - r).max() < 1e-4, (wide, np.abs(outs[wide] - r).max())
+        assert np.abs(outs['force'] - outs['0']).max() < 1e-4
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino4_wide', '0')
         emu_engine.set_option('wino_splitk', '1')
 
 

@@ -212,6 +212,71 @@ def test_conv_winograd_f4x4_tail_pieces(gpu_engine, case):
     assert y.shape == r.shape and d.max() < 1e-4 and 0 < frac < (1.01 if B * H < 200 else 0.5) and np.abs(y - r).max() < 2e-4
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 18, 22, 32, 128, 1), (1, 30, 40, 512, 512, 0), (10, 64, 64, 256, 256, 0), (32, 40, 40, 512, 512, 0),
+                                  (16, 80, 80, 128, 256, 1), (3, 62, 78, 128, 384, 0)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_conv_winograd_f4x4_wide_items(gpu_engine, case):
+    """conv_wino4w.hip (option wino4_wide, round 4; default off): Winograd F(4x4,3x3) with items of 16 tiles x 128 couts in 32-channel
+    steps, from the same packed filters as conv_wino4.hip.  Small ragged shapes, PoseNet2D's 30x40 maps, launches with tail pieces (a quarter
+    / an eighth of a round left), a pooled layer, three cout blocks.  Against conv_wino4.hip on the same input (the same products, another
+    summation order) and against conv_wino.hip (F(2x2,3x3), itself oracle-checked); deterministic; the counter proves which kernel ran."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case) + 31)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    gpu_engine.set_option('wino4', '1')
+    gpu_engine.set_option('wino_splitk', '0')
+    try:
+        gpu_engine.set_option('wino4_wide', 'force')
+        n0 = gpu_engine.counter('conv_wino4w_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino4w_launches') == n0 + 1
+        assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, bool(pool))), "not deterministic"
+        gpu_engine.set_option('wino4_wide', '0')
+        y4 = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert gpu_engine.counter('conv_wino4w_launches') == n0 + 2
+    finally:
+        gpu_engine.set_option('wino4_wide', '0')
+        gpu_engine.set_option('wino_splitk', '1')
+        gpu_engine.set_option('wino4', '0')
+    gpu_engine.set_option('conv_impl', 'winograd')
+    try:
+        r = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        gpu_engine.set_option('conv_impl', 'mfma')
+        gpu_engine.set_option('wino4', 'auto')
+    print("wide items %s: vs conv_wino4 %.2e, vs F(2x2,3x3) %.2e" % (case, np.abs(y - y4).max(), np.abs(y - r).max()))
+    assert y.shape == r.shape and np.abs(y - y4).max() < 1e-4 and np.abs(y - r).max() < 2e-4
+
+
+def test_full_pipeline_batch32_wide_items(gpu_engine, synth_weights):
+    """The whole path at the bench shape (B = 32, 320x320) with option wino4_wide = 1: the 3x3 trunk layers with Cout % 128 == 0 run on
+    conv_wino4w.hip (counter), everything else as by default.  Held against the default run of the same engine: same hand side decisions,
+    centres and crop scales (at most two knife-edge images may differ, as in test_full_pipeline_batch32_winograd_active), 3-D keypoints
+    within the path's 1e-4 bar, heat-maps within 1e-3."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=gpu_engine)
+    net.init_from_dict(synth_weights)
+    img = synth.make_batch(77, 32, 320, 320)
+    hs = synth.hand_sides(32)
+    base = net.inference(img, hs, True)
+    gpu_engine.set_option('wino4_wide', '1')
+    try:
+        n0 = gpu_engine.counter('conv_wino4w_launches')
+        out = net.inference(img, hs, True)
+        nw = gpu_engine.counter('conv_wino4w_launches') - n0
+    finally:
+        gpu_engine.set_option('wino4_wide', '0')
+    assert nw >= 10, nw          # (the layers with Cin >= 256: 7 of HandSegNet's, 4 of PoseNet2D's)
+    same = [i for i in range(32) if np.array_equal(out[3][i], base[3][i]) and np.array_equal(out[2][i], base[2][i])]
+    assert len(same) >= 30, len(same)
+    e3 = np.abs(out[5][same] - base[5][same]).max()
+    em = np.abs(out[4][same] - base[4][same]).max()
+    print("wide items, whole path: %d conv_wino4w launches, %d / 32 images with the default's crop, 3-D %.2e, heat-maps %.2e" % (nw, len(same), e3, em))
+    assert e3 < 1e-4 and em < 1e-3
+
+
 W4_CASES = [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 17, 21, 32, 64, 0, 3), (1, 30, 40, 512, 512, 0, 3),
             (1, 32, 32, 256, 256, 0, 3), (2, 60, 80, 128, 256, 1, 3), (3, 10, 6, 16, 64, 1, 3), (16, 64, 64, 256, 256, 0, 3), (16, 128, 128, 128, 128, 1, 3),
             (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7),

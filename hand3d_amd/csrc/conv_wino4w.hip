@@ -16,6 +16,7 @@
 // A plane is EIGHT pairs of MFMAs (channel half h, k quad e; both cout groups) with one memory instruction behind each.
 // Not here (stays on conv_wino4.hip): 7x7 filters, channel splits, Cout = 64 layers.
 #include "hp3d_common.h"
+#include "wino4_shared.h"
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -25,7 +26,7 @@ namespace {
 constexpr int WW_TILES = 16;                       // Winograd tiles (4x4 outputs each) per item
 constexpr int WW_CK = 32;                          // channels per step (two 16-channel steps of the packed filters)
 constexpr int WW_COUTS = 128;                      // output channels per item (32 per wave: two MFMA column groups)
-constexpr int WW_NP = 36;
+constexpr int WW_NP = W4_NP;
 constexpr int WW_PLANE_FLOATS = WW_TILES * WW_CK;  // 2 KB
 constexpr int WW_VBUF_FLOATS = WW_NP * WW_PLANE_FLOATS;
 constexpr int WW_SMEM_BYTES = 2 * WW_VBUF_FLOATS * 4 + 2 * 2 * WW_TILES * 4;
@@ -39,60 +40,12 @@ constexpr int WW_AGPR_PLANES = 32;
 constexpr int WW_TRANSFORM_AT = 29;
 constexpr int WW_PIECE_FLOATS = WW_TILES * 16 * WW_COUTS;       // raw 4x4 outputs of one item: [tile 16][pixel 16][cout 128] = 128 KB
 
-// window issue order: conv_wino4.hip's classes (the same pixels seen from neighbouring tiles follow each other)
-#define WW_ISSUE_ELEM(k) ((int[36]){0, 4, 24, 28, 1, 5, 25, 29, 2, 26, 3, 27, 6, 10, 30, 34, 7, 11, 31, 35, 8, 32, 9, 33, 12, 16, 13, 17, 14, 15, 18, 22, 19, 23, 20, 21}[(k)])
+#define WW_ISSUE_ELEM(k) W4_ISSUE_ELEM(k)          // window issue order: class by class (wino4_shared.h)
 
 __device__ __forceinline__ int ww_swz(int t) { return 2 * (((t >> 1) & 1) + 2 * (t >> 3)); }
 
-// B^T / A^T of F(4x4,3x3): conv_wino4.hip's (same association: the two kernels agree bit for bit per product; sums differ in order only
-// through the 32-channel step)
-__device__ __forceinline__ void ww_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
-    const f32x2 t0 = (4.f * x0 + x4) - 5.f * x2;
-    const f32x2 t5 = (4.f * x1 + x5) - 5.f * x3;
-    const f32x2 s12 = x1 + x2, d12 = x1 - x2, s34 = x3 + x4, d43 = x4 - x3, d31 = x3 - x1, d42 = x4 - x2;
-    x0 = t0;
-    x1 = s34 - 4.f * s12;
-    x2 = d43 + 4.f * d12;
-    x3 = d42 + 2.f * d31;
-    x4 = d42 - 2.f * d31;
-    x5 = t5;
-}
-__device__ __forceinline__ void ww_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
-    y0 = (m0 + s12) + s34;
-    y1 = d12 + 2.f * d34;
-    y2 = s12 + 4.f * s34;
-    y3 = (d12 + 8.f * d34) + m5;
-}
-
-struct WWGeom {
-    int TXn, TYn, per_img, tile_blocks, ncy;
-    __device__ __forceinline__ WWGeom(const ConvParams& p)
-        : TXn(p.tiles_x), TYn(p.tiles_y), per_img(p.tiles_x * p.tiles_y), tile_blocks((p.B * p.tiles_x * p.tiles_y + WW_TILES - 1) / WW_TILES),
-          ncy(p.Cout / WW_COUTS) {}
-    // flat tile id -> (image, tile row, tile column): bands of four tile rows, column-major inside a band (16 consecutive ids = a 4 x 4 tile patch)
-    __device__ __forceinline__ void tile_decode(int id, int& tb, int& tyy, int& txx) const {
-        tb = id / per_img;
-        const int r = id - tb * per_img;
-        const int band = r / (4 * TXn), rem = r - band * 4 * TXn;
-        const int rows = min(4, TYn - 4 * band);
-        txx = rem / rows;
-        tyy = band * 4 + rem - txx * rows;
-    }
-    // XCD-affine item order (conv_wino4.hip): within an XCD consecutive items are the cout blocks of one tile block
-    __device__ __forceinline__ void item_decode(int r, int& cy_, int& tb_) const {
-        const int aff = (tile_blocks >> 3) * 8 * ncy;
-        if (r < aff) {
-            const int xcd = r & 7, j = r >> 3, tbq = j / ncy;
-            cy_ = j - tbq * ncy;
-            tb_ = tbq * 8 + xcd;
-        } else {
-            const int q = r - aff, tbi = q / ncy;
-            cy_ = q - tbi * ncy;
-            tb_ = (tile_blocks & ~7) + tbi;
-        }
-    }
-};
+// B^T / A^T of F(4x4,3x3), tile / item geometry, tail reduction: wino4_shared.h (the same association as conv_wino4.hip: bit-identical products)
+using WWGeom = W4GeomT<WW_TILES, WW_COUTS>;
 
 // TAIL pieces as in conv_wino4.hip: virtual item ids [0, nfull) are whole items; nfull + 2 w + j = piece j of workgroup w's run of the
 // under-filled last round's item-steps (raw sums to the compact scratch [workgroup][piece 2][tile][pixel][cout], added by ww_tail_reduce).
@@ -157,9 +110,9 @@ void conv_wino4w_kernel(const ConvParams p) {
     float* const Vw = V + lt * WW_CK + ((lp >> 1) ^ ww_swz(lt)) * 4 + (lp & 1) * 2;      // this thread's slot in plane 0 of buffer 0
     auto transform_arith = [&]() {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) ww_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
+        for (int c = 0; c < 6; ++c) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
 #pragma unroll
-        for (int a = 0; a < 6; ++a) ww_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
+        for (int a = 0; a < 6; ++a) w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
     };
     auto v_write = [&](int buf, int pl) {
         float* Vq0 = Vw + buf * WW_VBUF_FLOATS;
@@ -348,12 +301,12 @@ void conv_wino4w_kernel(const ConvParams p) {
                 float z[6][4];
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
-                    ww_at(M[0 * 6 + b][g][r], M[1 * 6 + b][g][r], M[2 * 6 + b][g][r], M[3 * 6 + b][g][r], M[4 * 6 + b][g][r], M[5 * 6 + b][g][r],
+                    w4_at(M[0 * 6 + b][g][r], M[1 * 6 + b][g][r], M[2 * 6 + b][g][r], M[3 * 6 + b][g][r], M[4 * 6 + b][g][r], M[5 * 6 + b][g][r],
                           z[b][0], z[b][1], z[b][2], z[b][3]);
                 float y[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ww_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
+                    w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
                     if (!POOL && !raw) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -395,63 +348,10 @@ void conv_wino4w_kernel(const ConvParams p) {
     }
 }
 
-// Tail pieces -> outputs (conv_wino4.hip's reduction with this file's item shape)
+// Tail pieces -> outputs (wino4_shared.h: w4_tail_reduce_body with this file's item shape)
 template <bool POOL>
 HP3D_KERNEL(256)
-void ww_tail_reduce_kernel(const ConvParams p) {
-    const WWGeom geo(p);
-    const int nitems = geo.tile_blocks * geo.ncy, nfull = nitems - p.tail_items;
-    constexpr int PX = POOL ? 4 : 16;
-    const int Hs = POOL ? (p.Ho >> 1) : p.Ho, Ws = POOL ? (p.Wo >> 1) : p.Wo;
-    const long total = (long)p.tail_items * WW_TILES * PX * (WW_COUTS / 4);
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(e % (WW_COUTS / 4));
-        long r = e / (WW_COUTS / 4);
-        const int px = (int)(r % PX); r /= PX;
-        const int t = (int)(r % WW_TILES);
-        const int ti = (int)(r / WW_TILES);
-        int cy, tblock, img, ty, tx;
-        geo.item_decode(nfull + ti, cy, tblock);
-        geo.tile_decode(tblock * WW_TILES + t, img, ty, tx);
-        if (img >= p.B) continue;
-        const int co = cy * WW_COUTS + c4 * 4;
-        const int S = p.Cin / WW_CK, q = p.tail_q;
-        const int w_lo = (ti * S) / q, w_hi = ((ti + 1) * S - 1) / q;
-        const float* src = p.partial + (size_t)t * (16 * WW_COUTS) + c4 * 4;
-        auto slot_of = [&](int w) { return (size_t)(2 * w + (w * q >= ti * S ? 0 : 1)) * WW_PIECE_FLOATS; };
-        const f32x4 bias = *(const f32x4*)(p.bias + co);
-        f32x4 res;
-        int oy, ox;
-        if (POOL) {
-            const int pi = px >> 1, pj = px & 1;
-            oy = 2 * ty + pi; ox = 2 * tx + pj;
-            f32x4 mx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-                const int pix = (2 * pi + (qd >> 1)) * 4 + 2 * pj + (qd & 1);
-                f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                for (int w = w_lo; w <= w_hi; ++w) a += *(const f32x4*)(src + slot_of(w) + pix * WW_COUTS);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mx[j] = qd == 0 ? a[j] : fmaxf(mx[j], a[j]);
-            }
-            res = mx + bias;
-        } else {
-            oy = 4 * ty + (px >> 2); ox = 4 * tx + (px & 3);
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            for (int w = w_lo; w <= w_hi; ++w) a += *(const f32x4*)(src + slot_of(w) + px * WW_COUTS);
-            res = a + bias;
-        }
-        if (oy >= Hs || ox >= Ws) continue;
-        if (p.act) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) res[j] = fmaxf(res[j], HP3D_LEAKY_SLOPE * res[j]);
-        }
-        float* dst = p.out + ((size_t)(img * Hs + oy) * Ws + ox) * p.out_cs + co;
-        if (co + 3 < p.cout_store) *(f32x4*)dst = res;
-        else
-            for (int j = 0; j < 4; ++j) if (co + j < p.cout_store) dst[j] = res[j];
-    }
-}
+void ww_tail_reduce_kernel(const ConvParams p) { w4_tail_reduce_body<POOL, WW_TILES, WW_COUTS, WW_CK>(p, (long)blockIdx.x * blockDim.x + threadIdx.x, (long)gridDim.x * blockDim.x); }
 
 }  // namespace
 

@@ -21,6 +21,14 @@
 #include <cstring>
 #include <type_traits>
 
+#ifndef HP3D_WW_TIMING
+#define HP3D_WW_TIMING 0         // 1: diagnostic build (as conv_wino4.hip's HP3D_W4_TIMING): every wave sums shader-clock intervals of its steps into
+#endif                           // ww_timing[] -- planes 0..29 | transform | planes 30..35 | barrier | between steps / epilogue; the launcher prints them
+#if HP3D_WW_TIMING
+__device__ unsigned long long ww_timing[8];
+#define WW_CLOCK() __builtin_readcyclecounter()
+#endif
+
 namespace {
 
 constexpr int WW_TILES = 16;                       // Winograd tiles (4x4 outputs each) per item
@@ -190,6 +198,9 @@ void conv_wino4w_kernel(const ConvParams p) {
     for (int pl = 0; pl < WW_NP; ++pl) v_write(0, pl);
     __syncthreads();
     int cur = 0;
+#if HP3D_WW_TIMING
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, t_mark = WW_CLOCK();
+#endif
 
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_s0 = s0, n_s1 = s1, n_piece = -1;
@@ -203,6 +214,9 @@ void conv_wino4w_kernel(const ConvParams p) {
             const bool lasts = step + 1 == s1;
             const int nvoff = lasts ? n_wvoff : wvoff;
             const int nstep = lasts ? n_s0 : step + 1;
+#if HP3D_WW_TIMING
+            { const unsigned long long t = WW_CLOCK(); tsum[4] += t - t_mark; t_mark = t; }      // (item switch / epilogue / step prologue)
+#endif
             ab[0][0] = cur * (WW_VBUF_FLOATS * 4) + va_lane0;
             ab[1][0] = cur * (WW_VBUF_FLOATS * 4) + va_lane1;
             ab[0][1] = ab[0][0] + WW_HALF * WW_PLANE_FLOATS * 4;
@@ -261,10 +275,24 @@ void conv_wino4w_kernel(const ConvParams p) {
                         }
                     }
                 }
-                if (pl == WW_TRANSFORM_AT) transform_arith();
+                if (pl == WW_TRANSFORM_AT) {
+#if HP3D_WW_TIMING
+                    { const unsigned long long t = WW_CLOCK(); tsum[0] += t - t_mark; t_mark = t; }
+#endif
+                    transform_arith();
+#if HP3D_WW_TIMING
+                    { const unsigned long long t = WW_CLOCK(); tsum[1] += t - t_mark; t_mark = t; }
+#endif
+                }
             }
             HP3D_SCHED_BARRIER();
+#if HP3D_WW_TIMING
+            { const unsigned long long t = WW_CLOCK(); tsum[2] += t - t_mark; t_mark = t; }
+#endif
             __syncthreads();             // V[cur^1] complete, V[cur] free
+#if HP3D_WW_TIMING
+            { const unsigned long long t = WW_CLOCK(); tsum[3] += t - t_mark; t_mark = t; }
+#endif
             cur ^= 1;
         };
         {
@@ -343,6 +371,16 @@ void conv_wino4w_kernel(const ConvParams p) {
                 else store_tile(std::false_type{});
             }
         }
+#if HP3D_WW_TIMING
+        if (n_item < 0) {
+            const unsigned long long t = WW_CLOCK();
+            tsum[4] += t - t_mark;
+            if (lane == 0) {
+                for (int i = 0; i < 5; ++i) atomicAdd(&ww_timing[i], tsum[i]);
+                atomicAdd(&ww_timing[5], 1ull);
+            }
+        }
+#endif
         if (n_item < 0) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff; piece = n_piece; s0 = n_s0; s1 = n_s1;
     }
@@ -395,6 +433,20 @@ static void ww_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
     HP3D_LAUNCH(k, grid, dim3(256), WW_SMEM_BYTES, s, p);
 }
 
+#if HP3D_WW_TIMING
+static void ww_timing_report(const ConvParams& p, hipStream_t s, const char* what) {
+    unsigned long long h[8] = {};
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(ww_timing), sizeof(h));
+    if (h[5]) {
+        const double w = (double)h[5];
+        fprintf(stderr, "ww_timing %s Cin %d Cout %d %dx%d B %d: per wave (cycles) planes 0..29 %.0f | transform %.0f | planes 30..35 %.0f | barrier %.0f | "
+                        "between steps / epilogue %.0f | waves %.0f\n", what, p.Cin, p.Cout, p.Ho, p.Wo, p.B, h[0] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, w);
+    }
+    unsigned long long z[8] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(ww_timing), z, sizeof(z));
+}
+#endif
 int conv_wino4w_launch(const ConvParams& pin, int pool, hipStream_t s) {
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
     if (pin.nsub != 1 || pin.ksplit > 1 || pin.Cout % WW_COUTS || pin.Cin % WW_CK) return -1;
@@ -409,6 +461,9 @@ int conv_wino4w_launch(const ConvParams& pin, int pool, hipStream_t s) {
         p.tail_q = conv_wino4w_tail_plan(p.Cin, p.Cout, p.Ho, p.Wo, p.B, &p.tail_items);
     if (pool) ww_launch_t<true>(p, tiles, s);
     else ww_launch_t<false>(p, tiles, s);
+#if HP3D_WW_TIMING
+    ww_timing_report(p, s, pool ? "3x3 pool" : "3x3");
+#endif
     if (p.tail_items > 0) {
         const long total = (long)p.tail_items * WW_TILES * (pool ? 4 : 16) * (WW_COUTS / 4);
         const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -134,11 +134,15 @@ void conv_wino4w_kernel(const ConvParams p) {
     const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(WW_NP * p.Cin) * (unsigned)p.Cout * 4u);
     const int step16_stride_b = CO16 * 1024;
     const int plane_stride_b = 2 * nsteps * step16_stride_b;
-    auto soff_of = [&](int plane, int step, int h) { return plane * plane_stride_b + (2 * step + h) * step16_stride_b; };
+    // scalar offset of a fragment: plane, 16-channel step 2 s + h, and the wave's cout block `cyoff` (bytes).  The per-lane part of the address is
+    // the constant lane * 16: nothing about the NEXT item has to live in a vector register across the epilogue (a spilled VGPR reloaded there
+    // costs an s_waitcnt vmcnt(0) behind the epilogue's stores, i.e. a full drain of the store queue per item)
+    auto soff_of = [&](int plane, int step, int h, int cyoff) { return plane * plane_stride_b + (2 * step + h) * step16_stride_b + cyoff; };
+    const int wv_lane = lane * 16;
 
     f32x4 M[WW_NP][2];     // [plane][cout group]: rows = tiles 4 (lane >> 4) + r, column = cout 16 g + (lane & 15)
     f32x4 bq[WW_RING][2];  // [half-plane slot][cout group]
-    auto b_fetch1 = [&](int slot, int g, int voff, int soff) { bq[slot][g] = HP3D_BUFFER_LOAD16(wrsrc, voff + g * 1024, soff); };
+    auto b_fetch1 = [&](int slot, int g, int soff) { bq[slot][g] = HP3D_BUFFER_LOAD16(wrsrc, wv_lane + g * 1024, soff); };
     // A fragments: channel half h, k slot lq -> quad (4 h + lq) ^ s(tile); h flips bit 2 of the quad = byte offset ^ 64
     const int va_lane0 = (ln * WW_CK + ((lq ^ ww_swz(ln)) * 4)) * 4;
     const int va_lane1 = va_lane0 ^ 64;
@@ -185,13 +189,13 @@ void conv_wino4w_kernel(const ConvParams p) {
     s0 = HP3D_READFIRSTLANE(s0); s1 = HP3D_READFIRSTLANE(s1);
     loader_setup(tblock, true);
     table_write(tblock, 0, piece);
-    int wvoff = (cy * (WW_COUTS / 16) + wave * 2) * 1024 + lane * 16;
+    int cyoff = HP3D_READFIRSTLANE((cy * (WW_COUTS / 16) + wave * 2) * 1024);        // byte offset of this wave's two cout groups inside a (plane, step) block
 #pragma unroll
     for (int e = 0; e < 36; ++e) d[e] = HP3D_BUFFER_LOAD8(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), s0 * (WW_CK * 4));
 #pragma unroll
     for (int t = 0; t < WW_RING; ++t) {
-        b_fetch1(t, 0, wvoff, soff_of(t >> 1, s0, t & 1));
-        b_fetch1(t, 1, wvoff, soff_of(t >> 1, s0, t & 1));
+        b_fetch1(t, 0, soff_of(t >> 1, s0, t & 1, cyoff));
+        b_fetch1(t, 1, soff_of(t >> 1, s0, t & 1, cyoff));
     }
     transform_arith();
 #pragma unroll
@@ -203,16 +207,14 @@ void conv_wino4w_kernel(const ConvParams p) {
 #endif
 
     for (int k = 0;; ++k) {
-        int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_s0 = s0, n_s1 = s1, n_piece = -1;
+        int n_cy = cy, n_tblock = tblock, n_cyoff = cyoff, n_s0 = s0, n_s1 = s1, n_piece = -1;
         const int n_item = next_of(item);
         const bool raw = piece >= 0;
-        const int cout0 = cy * WW_COUTS + wave * 32 + ln;            // group g: + 16 g
-        const float bias0 = raw ? 0.f : p.bias[cout0], bias1 = raw ? 0.f : p.bias[cout0 + 16];
 
         auto step_body = [&](int step, auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool lasts = step + 1 == s1;
-            const int nvoff = lasts ? n_wvoff : wvoff;
+            const int ncyoff = lasts ? n_cyoff : cyoff;
             const int nstep = lasts ? n_s0 : step + 1;
 #if HP3D_WW_TIMING
             { const unsigned long long t = WW_CLOCK(); tsum[4] += t - t_mark; t_mark = t; }      // (item switch / epilogue / step prologue)
@@ -255,12 +257,12 @@ void conv_wino4w_kernel(const ConvParams p) {
                         const int tp = t >> 1, th = t & 1;
                         const int slot = (2 * pl + hh) % WW_RING;
                         if (gi != 5) {
-                            if (tp < WW_NP) b_fetch1(slot, 0, wvoff, soff_of(tp, step, th));
-                            else b_fetch1(slot, 0, nvoff, soff_of(tp - WW_NP, nstep, th));
+                            if (tp < WW_NP) b_fetch1(slot, 0, soff_of(tp, step, th, cyoff));
+                            else b_fetch1(slot, 0, soff_of(tp - WW_NP, nstep, th, ncyoff));
                         }
                         if (gi != 3) {
-                            if (tp < WW_NP) b_fetch1(slot, 1, wvoff, soff_of(tp, step, th));
-                            else b_fetch1(slot, 1, nvoff, soff_of(tp - WW_NP, nstep, th));
+                            if (tp < WW_NP) b_fetch1(slot, 1, soff_of(tp, step, th, cyoff));
+                            else b_fetch1(slot, 1, soff_of(tp - WW_NP, nstep, th, ncyoff));
                         }
                     } else if (gi == 2 || gi == 6) {
                         const int j = gi == 2 ? 0 : 1;
@@ -300,7 +302,7 @@ void conv_wino4w_kernel(const ConvParams p) {
             if (has_next) split_of(n_item, n_cy, n_tblock, n_piece, n_s0, n_s1);
             n_cy = HP3D_READFIRSTLANE(n_cy); n_tblock = HP3D_READFIRSTLANE(n_tblock); n_piece = HP3D_READFIRSTLANE(n_piece);
             n_s0 = HP3D_READFIRSTLANE(n_s0); n_s1 = HP3D_READFIRSTLANE(n_s1);
-            n_wvoff = (n_cy * (WW_COUTS / 16) + wave * 2) * 1024 + lane * 16;
+            n_cyoff = HP3D_READFIRSTLANE((n_cy * (WW_COUTS / 16) + wave * 2) * 1024);
         }
         step_body(s0, std::true_type{});
         table_write(n_tblock, (k + 1) & 1, n_piece);
@@ -310,13 +312,19 @@ void conv_wino4w_kernel(const ConvParams p) {
 #ifndef HP3D_EMU
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");       // MFMA results written inside inline asm: the hazard recogniser cannot see them
 #endif
+        // (the two bias values are loaded HERE, not before the steps: live across the plane loops they were spilled, and a spill reloaded
+        //  behind the first stores costs an s_waitcnt vmcnt(0) = a drain of the store queue)
+        const int cout0 = cy * WW_COUTS + wave * 32 + (int)(threadIdx.x & 15);            // group g: + 16 g
+        const float bias0 = raw ? 0.f : p.bias[cout0], bias1 = raw ? 0.f : p.bias[cout0 + 16];
         const int* tab = tinfo + (k & 1) * 2 * WW_TILES;
         const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0 || raw) ? 1 : 0) != 0;
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(raw ? (float*)p.partial : p.out, raw ? 2u * gridDim.x * (unsigned)(WW_PIECE_FLOATS * 4) : out_bytes);
         const int srow = raw ? 4 * WW_COUTS * 4 : Ws * p.out_cs * 4, scol = raw ? WW_COUTS * 4 : p.out_cs * 4;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int cout = cout0 + 16 * g;
+            int tx = (int)threadIdx.x;
+            HP3D_OPAQUE_V(tx);                               // (recomputed per group on purpose: kept live from group 0 it is spilled and reloaded behind 128 stores)
+            const int cout = cy * WW_COUTS + wave * 32 + 16 * g + (tx & 15);
             const float bias = g ? bias1 : bias0;
             const bool cok = raw || cout < p.cout_store;
             const int cout_off = raw ? wave * 32 + 16 * g + ln : cout;
@@ -382,7 +390,7 @@ void conv_wino4w_kernel(const ConvParams p) {
         }
 #endif
         if (n_item < 0) break;
-        item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff; piece = n_piece; s0 = n_s0; s1 = n_s1;
+        item = n_item; cy = n_cy; tblock = n_tblock; cyoff = n_cyoff; piece = n_piece; s0 = n_s0; s1 = n_s1;
     }
 }
 

@@ -76,13 +76,19 @@ def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
     net2 = ColorHandPose3DNetwork(engine=e2)
     net2.init(None, weight_files=[npz])
     assert e2.nets_mask() & 15 == 15
+    # the same engine state: every net gives the same bits (stage by stage on small inputs -- the whole path would put a 256 x 256 crop
+    # through the interpreter twice: two minutes)
     rng = np.random.RandomState(5)
     img = (rng.rand(1, 16, 24, 3).astype(np.float32) - 0.5)
     hs = np.array([[1., 0.]], np.float32)
-    a = net.inference(img, hs, True)
-    b = net2.inference(img, hs, True)
-    for x, y in zip(a, b):
-        assert np.array_equal(x, y)
+    sm = (rng.randn(1, 32, 32, 21) * 0.3).astype(np.float32)
+    for ea, eb, na, nb in ((emu_engine, e2, net, net2),):
+        for x, y in zip(ea.handsegnet(img, want_small=True), eb.handsegnet(img, want_small=True)):
+            assert np.array_equal(x, y)
+        for x, y in zip(na.inference_pose2d(img[:, :16, :16]), nb.inference_pose2d(img[:, :16, :16])):
+            assert np.array_equal(x, y)
+        for x, y in zip(ea.pose3d(sm, hs), eb.pose3d(sm, hs)):
+            assert np.array_equal(x, y)
     e3 = Engine(0, path=emu_engine.lib._name)
     net3 = ColorHandPose3DNetwork(engine=e3)
     net3.init(None, weight_files=[npz], exclude_var_list=['PosePrior', 'ViewpointNet'])

@@ -1,4 +1,4 @@
-// conv_h16.hip -- 3x3 / stride-1 / SAME convolution in half precision (f16 operands, float32 accumulate) for the
+// conv_h16.hip -- 3x3 (round 4: also 7x7 and 1x1) / stride-1 / SAME convolution in half precision (f16 operands, float32 accumulate) for the
 // half-precision trunks of BASELINE config 5: bias + leaky-ReLU (+ 2x2 max-pool) fused, halves out.
 //
 // Same call sites as conv_mfma.hip's F16 instantiations (NetworkOps.conv_relu + max_pool, utils/general.py:36-65; trunk layer
@@ -21,8 +21,10 @@
 //     to half, transposes through per-wave LDS slabs and stores 16 bytes per lane with a pixel's couts contiguous (the pooled
 //     form takes the max of the four pixels' half vectors on the way);
 //   * persistent grid over (image, tile, cout block) items; edges and ragged tiles are out-of-range buffer offsets.
-// Measured (profiles/r02_h16_counters.md): 0.43-0.49 of the 2.5 PF dense peak per instantiation at the config-5 shape; the
-// matrix pipe is busy 0.65-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
+//   * round 4: the filter size is a template parameter KS -- PoseNet2D's 7x7 score-map stages (nets/ColorHandPose3DNetwork.py:206-215) and the 1x1
+//     layers with >= 64 couts take the single-buffer forms with a patch of (16 + KS - 1)^2 pixels and 4 KS^2 K-steps per chunk.
+// Measured (profiles/r04_h16_counters.md): 0.42-0.48 of the 2.5 PF dense peak per 3x3 instantiation at the config-5 shape (the 7x7 form: 0.53); the
+// matrix pipe is busy 0.66-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
 #include "hp3d_common.h"
 #include <algorithm>
 #ifndef HP3D_H16_ABL
@@ -32,7 +34,7 @@
 namespace {
 
 constexpr int HT = 16;                    // output tile: 16 x 16 pixels
-constexpr int HPW = HT + 2;               // patch width / height (halo 1)
+constexpr int HPW = HT + 2;               // patch width / height (halo 1) -- these are the 3x3 values; the kernel derives its own from KS
 constexpr int HPITCH = 36;                // floats per patch pixel: 64 halves = 32 floats + 4 pad (144 B: conflict-free b128)
 constexpr int HPATCH_FLOATS = HPW * HPW * HPITCH;        // 11664 floats = 46.7 KB per buffer
 constexpr int HPIECES = HPW * HPW * 8;    // 16-byte pieces per patch

@@ -131,12 +131,12 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_p
     """The miscompile of round 2 (profiles/r02_tuning_notes.md, "conv_wino"): when hipcc cannot prove a buffer load's scalar offset
     wave-uniform it wraps the load in a waterfall loop (v_readfirstlane ... s_and_saveexec ... s_cbranch_execnz), and one such build
     returned WRONG 7x7 results on the GPU while the CPU interpreter of the same source was right.  So the shipped code object is
-    disassembled: in every conv_wino / conv_wino2 / conv_h16 kernel (a) no s_cbranch_execnz sits within a few instructions of a buffer load
+    disassembled: in every conv_wino / conv_wino2 / conv_wino4 / conv_wino4w / conv_h16 kernel (a) no s_cbranch_execnz sits within a few instructions of a buffer load
     (no waterfall loop), and (b) no scratch access lies inside the MFMA phase of a step / chunk loop (a spilled accumulator or
     address there drains the weight ring and has produced the slow builds recorded in the tuning notes)."""
     kernels = _kernel_disassembly(tmp_path)
-    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[24]?_kernel|conv_h16_kernel', k)}
-    assert len(hot) >= 8, sorted(kernels)[:20]
+    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[24]?w?_kernel|conv_h16_kernel', k)}
+    assert len(hot) >= 10 and any('conv_wino4w' in k for k in hot), sorted(kernels)[:20]
     for name, ins in hot.items():
         ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]
         n_mfma = sum(o.startswith('v_mfma') for o in ops)

@@ -696,7 +696,7 @@ def test_full_pipeline_batch32_winograd_active(net, synth_weights):
     net.engine.infer_full(img, hs)
     prof = net.engine.profile()
     net.engine.set_profiling(0)
-    w4 = [n for n, k, _, _, _ in prof if k.startswith('conv_wino4_')]
+    w4 = [n for n, k, _, _, _ in prof if k.startswith(('conv_wino4_', 'conv_wino4w_'))]          # (the wide-item form counts: same arithmetic, option wino4_wide)
     assert len(w4) >= 36 and 'HandSegNet/conv3_2' in w4 and 'PoseNet2D/conv4_2' in w4 and 'PoseNet2D/conv6_3' in w4, sorted(set(k for _, k, _, _, _ in prof))
     assert not [k for _, k, _, _, _ in prof if k.startswith(('conv_wino_', 'conv_wino2_'))], "a trunk layer fell back to an F(2x2,3x3) kernel"
     ev = EvalUtil()

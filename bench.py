@@ -53,6 +53,9 @@ def parse():
     ap.add_argument('--graph', action='store_true', help='replay each step as one hipGraph (hp3d_set_option graph=1)')
     ap.add_argument('--option', action='append', default=[], metavar='KEY=VALUE', help='hp3d_set_option before the run (repeatable)')
     ap.add_argument('--no-host-path', action='store_true', help='skip the PCIe-inclusive host_path measurement')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help="skip the `other_configs` leg (BASELINE.json's other configurations, measured after the primary line)")
+    ap.add_argument('--no-pin', action='store_true', help='do not pin this rank to the CPUs of its GPU\'s NUMA node')
     return ap.parse_args()
 
 
@@ -175,6 +178,190 @@ def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s, alg_flop_per_imag
     return cpu, par
 
 
+CONV_FAMILIES = ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')
+
+
+def families(rows):
+    """Per-launch profile rows (name, kernel, ms, flops, bytes) -> {family: [ms, flops, bytes, launches, executed flops]}, total ms.
+    Families: conv_wino / conv_wino2 (Winograd F(2x2,3x3) forms of the 3x3 / 7x7 layers), conv_wino4 (F(4x4,3x3), incl. the wide-item
+    and 16-tile forms), conv_mfma (direct implicit GEMM), conv_h16 (half-precision trunk kernel incl. its pooled, fused-first-block,
+    7x7 and 1x1 forms), conv_first (conv1_1), everything else under its own kernel name."""
+    fam = {}
+    for name, kern, ms, fl, by in rows:
+        k = ('conv_wino4' if kern.startswith('conv_wino4') else 'conv_wino2' if kern.startswith('conv_wino2') else
+             'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
+             'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
+        # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
+        # nine 3x3 blocks of its zero-extended 9x9 form, minus the structurally zero planes of the edge blocks (round 3):
+        # (4*16 + 4*12 + 9) = 121 plane products per 4*49
+        # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks minus
+        # their structurally zero planes: (4*36 + 4*30 + 25) = 289 plane products per 16*49
+        exe = ((289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
+               (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k in ('conv_wino', 'conv_wino2') else 1.0)
+        f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
+        f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
+    return fam, max(sum(v[0] for v in fam.values()), 1e-9)
+
+
+def roof_of_family(fam, k, total_ms, peak):
+    ms, fl, by, n, fle = fam[k]
+    sec = ms * 1e-3
+    if k == 'conv_first_3x3_c3':          # the one HBM-bound convolution (0.2 GFLOP per 13 MB of output per image)
+        ach = by / sec / 1e9 if sec > 0 else 0.0
+        return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                "frac": round(ach / PEAK_HBM_GBPS, 4), "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
+                "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2), "share_of_gpu_time": round(ms / total_ms, 4)}
+    alg = fl / sec / 1e12 if sec > 0 else 0.0
+    exe = fle / sec / 1e12 if sec > 0 else 0.0
+    # `achieved` / `frac` = what the matrix cores EXECUTE against their dense peak (<= 1 by construction);
+    # `achieved_algorithmic` = direct-form FLOPs (SURVEY.md 8d) / time, which Winograd lifts above the executed rate
+    return {"bound": "mfma", "kernel": k, "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(exe / peak, 4), "achieved_algorithmic": round(alg, 2),
+            "algorithmic_over_executed": round(alg / exe, 3) if exe > 0 else None,
+            "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
+            "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
+            "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
+            "share_of_gpu_time": round(ms / total_ms, 4)}
+
+
+def measure_config(eng, tag, what, call_site, workload, B, H, W, steps, warmup, dtype, img_np, hs_np):
+    """One BASELINE.json configuration on an engine whose weights are already finalized: W warm-up steps, K timed steps
+    (inputs resident in HBM, per-launch profiling off, device sync after every step as in the primary line), then a separate
+    event-timed pass for the dominant conv family and its executed fraction of the dense matrix-core peak.  Returns the record
+    and the device outputs of one more, untimed call (for the parity spot check)."""
+    from hand3d_amd import arch
+    d_img, d_hs = eng.to_device(img_np), eng.to_device(hs_np)
+    d_coord = eng.dev_alloc(B * 63 * 4)
+    d_kphw = eng.dev_alloc(B * 42 * 8)
+    d_kpmap = eng.dev_alloc(B * 256 * 256 * 21 * 4) if workload == 'full' else None
+    d_sm = [eng.dev_alloc(B * 32 * 32 * 21 * 4) for _ in range(3)] if workload == 'posenet' else None
+    eng.sync()
+
+    def step():
+        if workload == 'full':
+            eng.infer_full_dev(B, H, W, int(d_img), int(d_hs), kpmap=int(d_kpmap), coord3d=int(d_coord), kp_hw=int(d_kphw))
+        else:
+            eng.lib.hp3d_posenet2d_dev(eng.h, B, 256, 256, int(d_img), int(d_sm[0]), int(d_sm[1]), int(d_sm[2]))
+        eng.sync()
+
+    eng.set_profiling(0)
+    for _ in range(warmup):
+        step()
+    eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    eng.sync()
+    dt = time.perf_counter() - t0
+    psteps = max(1, min(steps, 5))
+    eng.set_profiling(2)
+    for _ in range(psteps):
+        step()
+    eng.sync()
+    rows = eng.profile()
+    eng.set_profiling(0)
+    fam, total_ms = families(rows)
+    conv = [k for k in fam if k in CONV_FAMILIES]
+    dom = max(conv, key=lambda k: fam[k][0])
+    roof = roof_of_family(fam, dom, total_ms, PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_F16_MFMA_TFLOPS)
+    fl = arch.pipeline_flops(H, W)
+    rec = {"config": tag, "what": what, "call_site": call_site, "dtype": dtype, "batch": B, "height": H, "width": W,
+           "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
+           "alg_gflop_per_image": round((fl['total'] if workload == 'full' else fl['posenet']) / 1e9, 2),
+           "dominant_family": dom, "executed_frac_of_dense_peak": roof["frac"], "executed_tflops": roof["achieved"],
+           "family_share_of_gpu_time": roof["share_of_gpu_time"], "profiled_ms_per_step": round(total_ms / psteps, 4)}
+    step()
+    out = {}
+    if workload == 'full':
+        out['coord3d'] = eng.to_host(d_coord, (B, 21, 3))
+        out['sm32'] = eng.to_host(d_kpmap, (1, 256, 256, 21))[:, ::8, ::8]
+    else:
+        out['sm32'] = eng.to_host(d_sm[2], (B, 32, 32, 21))
+    for b in [d_img, d_hs, d_coord, d_kphw, d_kpmap] + (d_sm or []):
+        if b is not None:
+            b.free()
+    return rec, out
+
+
+def other_configs(eng, weights, a, device):
+    """BASELINE.json's OTHER configurations from the command the driver runs: C1 (run.py's call, B = 1 at
+    240x320), C2 (eval2d_gt_cropped.py's PoseNet2D-only call, B = 1), the C4 per-GPU shard at eval_full.py's input size (B = 32 at
+    240x320), and C5's per-GPU shape (B = 128 at 480x640, half-precision trunks; on a second context of the same device).  Each
+    entry: images/s and ms/step of its own timed region, the dominant conv family with its executed fraction of the dense
+    matrix-core peak (separate event-timed pass), and a ONE-image parity spot check -- float32: the strict oracle on image 0
+    (heat-maps 1e-3, 3-D keypoints 1e-4); C5: the committed oracle fixture's segmentation logits (2e-3,
+    tests/test_gpu_c5_fixture.py's gate).  The oracle is the checker here, never the thing timed."""
+    from hand3d_amd import Engine, synth
+    want_parity = a.cpu_seconds > 0
+    res = []
+
+    def spot(workload, img, hs, out):
+        if not want_parity:
+            return None
+        from oracle import nets as onets
+        from oracle import tf_ops as OT
+        OT.CONV_BACKEND = 'torch'
+        try:
+            if workload == 'full':
+                o = onets.inference(weights, img[0:1], hs[0:1], True)
+                return {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[4][0, ::8, ::8] - out['sm32'][0]).max()),
+                        "tolerance_heatmap": 1e-3, "max_abs_err_kp3d": float(np.abs(o[5][0] - out['coord3d'][0]).max()),
+                        "tolerance_kp3d": 1e-4, "against": "oracle/nets.py:inference (float64-accumulating restatement)"}
+            o = onets.posenet2d(weights, img[0:1])
+            return {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[2][0] - out['sm32'][0]).max()), "tolerance_heatmap": 1e-3,
+                    "against": "oracle/nets.py:posenet2d"}
+        finally:
+            OT.CONV_BACKEND = 'numpy'
+
+    plan = [
+        ('C1', 'run.py forward pass shape: inference(), B=1, 240x320, f32', 'run.py:44-46', 'full', 1, 240, 320, 50, 10, 0),
+        ('C2', 'PoseNet2D only on a ground-truth crop: inference_pose2d(), B=1, 256x256, f32', 'eval2d_gt_cropped.py:44-46', 'posenet', 1, 256, 256, 50, 10, 100),
+        ('C4-shard@240x320', "config 4's per-GPU shard at eval_full.py's input size: inference(), B=32, 240x320, f32", 'eval_full.py:50-57', 'full', 32, 240, 320, 10, 3, 300),
+    ]
+    for tag, what, site, workload, B, H, W, steps, warmup, seed in plan:
+        try:
+            img = synth.make_batch(seed, B, H, W)
+            hs = synth.hand_sides(B)
+            rec, out = measure_config(eng, tag, what, site, workload, B, H, W, steps, warmup, 'f32', img, hs)
+            rec["parity_spot"] = spot(workload, img, hs, out)
+            res.append(rec)
+        except Exception as e:            # one configuration failing must not take the primary line with it
+            res.append({"config": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    # ---- C5 per-GPU shape: half-precision trunks on a second context (own weights blob, own arena: ~25 GB of the 288 GB)
+    eng16 = None
+    try:
+        eng16 = Engine(device)
+        eng16.load_weight_dict(weights)
+        eng16.finalize_weights('f16')
+        B, H, W = 128, 480, 640
+        # SURVEY.md 8d C5: uniform noise frames, seed 1000 + i; 16 distinct frames tiled 8x (host-side generation time, not GPU work)
+        base = np.stack([np.random.default_rng(1000 + i).uniform(-0.5, 0.5, size=(H, W, 3)).astype(np.float32) for i in range(16)], 0)
+        img = np.concatenate([base] * (B // 16), 0)
+        hs = synth.hand_sides(B)
+        rec, _ = measure_config(eng16, 'C5-shard', "config 5's per-GPU shape: inference(), B=128, 480x640, f16 trunks (f32 accumulate, f32 heads / "
+                                "lifting / outputs)", 'run.py:44-46 at 480x640', 'full', B, H, W, 3, 1, 'f16', img, hs)
+        rec["data"] = "16 distinct U(-0.5,0.5) frames (seeds 1000..1015) tiled to 128"
+        fix = os.path.join(ROOT, 'tests', 'golden', 'c5_f16_480x640.npz')
+        if want_parity and os.path.exists(fix):
+            g = np.load(fix)
+            n_img = int(g['seg_small'].shape[0])
+            fimg = synth.make_batch(int(g['seed0']), n_img, H, W)
+            eng16.set_option('f16_impl', 'h16_force')        # the kernels the B = 128 shape runs on, also at the fixture's 2 images
+            _, small = eng16.handsegnet(fimg, want_small=True)
+            eng16.set_option('f16_impl', 'h16')
+            rec["parity_spot"] = {"images": n_img, "max_abs_err_seg_logits": float(np.abs(small - g['seg_small']).max()), "tolerance": 2e-3,
+                                  "against": "tests/golden/c5_f16_480x640.npz (oracle with the f16 rounding points, scripts/make_c5_fixture.py)"}
+        else:
+            rec["parity_spot"] = None
+        res.append(rec)
+    except Exception as e:
+        res.append({"config": "C5-shard", "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
+    finally:
+        if eng16 is not None:
+            eng16.close()
+    return res
+
+
 def traffic_record(dom, workload_str, dtype):
     """HBM bytes per launch of the dominant kernel come from rocprofv3 PMC passes of THIS command (counters cannot be read
     in-process): scripts/gpu_round.sh <tag> pmc -> scripts/summarize_prof.py -> profiles/<family>_traffic.json.  The number
@@ -255,26 +442,84 @@ def self_launch(a):
     return 0 if not bad else max(abs(rc) for rc in bad)
 
 
-def visible_devices():
-    """HIP devices this process can see, through the C ABI (hp3d_device_count: no context, no torch)."""
+def visible_devices(isolated=False):
+    """HIP devices this process can see, through the C ABI (hp3d_device_count: no context, no torch).  `isolated`: ask in a
+    short-lived forked child, so that THIS process never initialises the HIP runtime (the self-launch parent only starts ranks
+    and must not sit on every GPU while they are measured)."""
     from hand3d_amd import _lib
-    return _lib.device_count()
+    if not isolated:
+        return _lib.device_count()
+    import multiprocessing as mp
+    ctx = mp.get_context('fork')
+    rd, wr = ctx.Pipe(duplex=False)
+
+    def probe():
+        try:
+            wr.send(int(_lib.device_count()))
+        except Exception:
+            wr.send(-1)
+    pr = ctx.Process(target=probe)
+    pr.start()
+    n = rd.recv() if rd.poll(120) else -1
+    pr.join(10)
+    if n < 0:
+        raise RuntimeError('hp3d_device_count failed in the probe process')
+    return n
+
+
+def pin_to_gpu_numa(device):
+    """Pin this rank to the CPUs of its GPU's NUMA node (host dispatch is what limits batch-shard scaling, and a
+    rank whose launch thread sits on the far socket pays for every one of its ~85 launches per step).  PCI address from
+    hp3d_device_pci_bus_id, node from /sys/bus/pci/devices/<addr>/numa_node, CPUs from /sys/devices/system/node/nodeN/cpulist,
+    intersected with the affinity the launcher / cgroup already allows.  Returns a description for `config`, None when the
+    sysfs entries are absent, the node is -1 or the intersection is empty (then nothing is changed)."""
+    try:
+        from hand3d_amd import _lib
+        addr = _lib.device_pci_bus_id(device).lower()
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % addr).read().strip())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open('/sys/devices/system/node/node%d/cpulist' % node).read().strip().split(','):
+            lo, _, hi = part.partition('-')
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if not allowed:
+            return None
+        os.sched_setaffinity(0, allowed)
+        return {"pci": addr, "numa_node": node, "cpus": len(allowed)}
+    except Exception:
+        return None
 
 
 def main():
     a = parse()
+    # ROCr reads its flags when the HIP runtime initialises (the first HIP call of the process, hp3d_device_count included): the
+    # dmabuf-IPC switch RCCL needs on this driver must be in the environment BEFORE that, also for ranks an external launcher started
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
     # `--gpus N` on a box that shows fewer than N devices: say so in ONE line and leave with a code of its own BEFORE any rank starts
-    # (self-launched) / before this rank joins the rendezvous (under a launcher) -- not N - n ranks dying one by one inside a
-    # rendezvous while the others wait for their timeout
-    ndev = visible_devices()
-    if ndev < a.gpus:
-        sys.stderr.write('bench.py: --gpus %d but only %d HIP device(s) are visible to this process (hp3d_device_count; check '
-                         'HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): not starting\n' % (a.gpus, ndev))
-        sys.exit(3)
+    # (self-launch parent: counted in a forked probe, the parent itself never touches HIP) -- not N - n ranks dying one by one inside a
+    # rendezvous while the others wait for their timeout.  A rank under a launcher only needs ITS device (LOCAL_RANK): with per-rank
+    # HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES isolation or a multi-node world it legitimately sees fewer devices than WORLD_SIZE.
+    if launched:
+        ndev = visible_devices()
+        if local >= ndev:
+            sys.stderr.write('bench.py: rank %d has LOCAL_RANK %d but only %d HIP device(s) are visible to this process '
+                             '(hp3d_device_count; check HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): not joining\n' % (rank, local, ndev))
+            sys.exit(3)
+    else:
+        ndev = visible_devices(isolated=a.gpus > 1)
+        if ndev < a.gpus:
+            sys.stderr.write('bench.py: --gpus %d but only %d HIP device(s) are visible to this process (hp3d_device_count; check '
+                             'HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES): not starting\n' % (a.gpus, ndev))
+            sys.exit(3)
     if a.gpus > 1 and not launched:
         sys.exit(self_launch(a))
-    if launched and int(os.environ.get('WORLD_SIZE', '1')) != a.gpus:
+    if launched and world != a.gpus:
         sys.stderr.write('bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: refusing to report a line whose '
                          'n_gpus would not be what was asked for\n' % (a.gpus, os.environ.get('WORLD_SIZE', '1')))
         sys.exit(2)
@@ -283,10 +528,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # multi-rank runs: every rank on the CPUs next to its GPU (before the engine starts its threads); recorded in `config`
+    affinity = pin_to_gpu_numa(local) if (launched and not a.no_pin) else None
 
     from hand3d_amd import Engine, synth, arch
     from hand3d_amd.dist import Rendezvous, ShardedPipeline
@@ -365,44 +608,11 @@ def main():
     eng.set_profiling(0)
 
     if rank == 0:
-        # families: conv_wino (Winograd F(2x2,3x3) form of the 3x3 / 7x7 layers), conv_mfma (direct implicit GEMM), conv_h16 (the
-        # half-precision 3x3 trunk kernel incl. its pooled and fused-first-block forms), conv_first (conv1_1), glue
-        fam = {}
-        for name, kern, ms, fl, by in rows:
-            k = ('conv_wino4' if kern.startswith('conv_wino4') else 'conv_wino2' if kern.startswith('conv_wino2') else
-                 'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
-                 'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
-            # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
-            # nine 3x3 blocks of its zero-extended 9x9 form, minus the structurally zero planes of the edge blocks (round 3):
-            # (4*16 + 4*12 + 9) = 121 plane products per 4*49
-            # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks minus
-            # their structurally zero planes: (4*36 + 4*30 + 25) = 289 plane products per 16*49
-            exe = ((289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
-                   (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k in ('conv_wino', 'conv_wino2') else 1.0)
-            f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
-            f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
-        total_ms = max(sum(v[0] for v in fam.values()), 1e-9)
+        fam, total_ms = families(rows)
         peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_F16_MFMA_TFLOPS
 
         def roof_of(k):
-            ms, fl, by, n, fle = fam[k]
-            sec = ms * 1e-3
-            if k == 'conv_first_3x3_c3':          # the one HBM-bound convolution (0.2 GFLOP per 13 MB of output per image)
-                ach = by / sec / 1e9 if sec > 0 else 0.0
-                return {"bound": "hbm", "kernel": k, "achieved": round(ach, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                        "frac": round(ach / PEAK_HBM_GBPS, 4), "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
-                        "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2), "share_of_gpu_time": round(ms / total_ms, 4)}
-            alg = fl / sec / 1e12 if sec > 0 else 0.0
-            exe = fle / sec / 1e12 if sec > 0 else 0.0
-            # `achieved` / `frac` = what the matrix cores EXECUTE against their dense peak (<= 1 by construction);
-            # `achieved_algorithmic` = direct-form FLOPs / time, which Winograd lifts above the executed rate
-            return {"bound": "mfma", "kernel": k, "achieved": round(exe, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(exe / peak, 4), "achieved_algorithmic": round(alg, 2),
-                    "algorithmic_over_executed": round(alg / exe, 3) if exe > 0 else None,
-                    "launches": n, "avg_launch_ms": round(ms / max(n, 1), 4),
-                    "alg_gflop_per_launch": round(fl / max(n, 1) / 1e9, 3),
-                    "alg_mbytes_per_launch": round(by / max(n, 1) / 1e6, 2),
-                    "share_of_gpu_time": round(ms / total_ms, 4)}
+            return roof_of_family(fam, k, total_ms, peak)
         dom = max(fam, key=lambda k: fam[k][0])
         roof = roof_of(dom)
         if dom == 'conv_h16':
@@ -421,7 +631,7 @@ def main():
         roof["timing"] = "HIP events on the engine stream around each launch, separate pass of %d steps (%.3f ms/step profiled)" % (
             a.steps, dt_prof / a.steps * 1e3)
         others = [roof_of(k) for k in sorted(fam, key=lambda k: -fam[k][0])
-                  if k != dom and k in ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')]
+                  if k != dom and k in CONV_FAMILIES]
         if a.layers:
             agg = {}
             for name, kern, ms_, fl_, by_ in rows:
@@ -483,10 +693,15 @@ def main():
                        "parallelism": "batch-shard x%d, one process per GPU, no data-path collective; weights by hp3d_bcast_weights "
                                       "and a per-step keypoint all-gather (RCCL through the C ABI, TCP rendezvous; no torch)" % world,
                        "comm": comm_mode, "rccl_ranks": rccl_ranks, "hipgraph": bool(a.graph), "options": a.option,
+                       "cpu_affinity": affinity,
                        "alg_gflop_per_image": round((fl_img['total'] if a.workload == 'full' else fl_img['posenet']) / 1e9, 2)},
             "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu, "epe_vs_oracle": parity,
             "host_path": host_path,
         }
+        if world == 1 and a.workload == 'full' and a.dtype == 'f32' and not a.no_other_configs:
+            t_oc = time.perf_counter()
+            res["other_configs"] = other_configs(eng, weights, a, local)
+            res["other_configs_wall_s"] = round(time.perf_counter() - t_oc, 1)
         if a.graph:
             res["config"]["hipgraph_replays"] = eng.counter('graph_replays')
         os.write(json_fd, (json.dumps(res) + '\n').encode())

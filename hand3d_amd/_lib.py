@@ -24,6 +24,7 @@ _ctx = C.c_void_p
 _SIGNATURES = {
     'hp3d_abi_version': (C.c_int, []),
     'hp3d_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'hp3d_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     'hp3d_create': (C.c_int, [C.c_int, C.POINTER(_ctx)]),
     'hp3d_destroy': (C.c_int, [_ctx]),
     'hp3d_last_error': (C.c_char_p, [_ctx]),
@@ -124,6 +125,15 @@ def device_count(path=None):
     n = C.c_int(0)
     rc = load(path).hp3d_device_count(C.byref(n))
     return int(n.value) if rc == 0 else 0
+
+
+def device_pci_bus_id(device, path=None):
+    """PCI address 'dddd:bb:dd.f' of HIP device `device` (hp3d_device_pci_bus_id); raises Hp3dError when the runtime has none."""
+    buf = C.create_string_buffer(32)
+    rc = load(path).hp3d_device_pci_bus_id(int(device), buf, 32)
+    if rc != 0:
+        raise Hp3dError('hp3d_device_pci_bus_id(%d) failed: %d' % (device, rc))
+    return buf.value.decode()
 
 
 def _ptr(a):

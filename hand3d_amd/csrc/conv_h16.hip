@@ -37,10 +37,7 @@ constexpr int HT = 16;                    // output tile: 16 x 16 pixels
 constexpr int HPW = HT + 2;               // patch width / height (halo 1) -- these are the 3x3 values; the kernel derives its own from KS
 constexpr int HPITCH = 36;                // floats per patch pixel: 64 halves = 32 floats + 4 pad (144 B: conflict-free b128)
 constexpr int HPATCH_FLOATS = HPW * HPW * HPITCH;        // 11664 floats = 46.7 KB per buffer
-constexpr int HPIECES = HPW * HPW * 8;    // 16-byte pieces per patch
-constexpr int HPVEC = (HPIECES + 255) / 256;             // pieces per thread (11)
-constexpr int HPGS = 4, HPG = (HPVEC + HPGS - 1) / HPGS;  // patch pieces per group, groups (3)
-constexpr int HPSTEP = 36 / HPG;         // K-steps between the fetches of successive groups
+constexpr int HPGS = 4;                    // patch pieces per group (the kernel derives the group count HPG from its filter size)
 #ifndef HP3D_H16_RING
 #define HP3D_H16_RING 6
 #endif
@@ -155,7 +152,7 @@ void conv_h16_kernel(const ConvParams p) {
         const int cb = it % ncb; it /= ncb;
         const int tx = it % tiles_x; it /= tiles_x;
         const int ty = it % tiles_y;
-        const int b = it / tiles_y;
+        [[maybe_unused]] const int b = it / tiles_y;          // (the host pass sees the buffer-descriptor stand-ins only)
         const int oy0 = ty * HT, ox0 = tx * HT;
         // this thread's patch pieces: piece idx -> (patch pixel, 16-byte slot) -> byte offset inside image b; SAME padding,
         // the image edge and idx past the patch get an out-of-range offset, which a buffer load answers with zeros.

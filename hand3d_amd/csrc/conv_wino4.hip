@@ -168,7 +168,7 @@ void conv_wino4_kernel(const ConvParams p) {
     };
     auto loader_shift = [&](int sub) { window_offsets(true, cb, cty, ctx_, sub); };
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
-    const unsigned out_bytes = (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u;
+    [[maybe_unused]] const unsigned out_bytes = (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 4u;
 
     f32x2 d[36];
     auto window_fetch = [&](int soff) {
@@ -635,6 +635,8 @@ static void wino4_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
 
 // pin.ksplit > 1: pin.out must be the partial-sum scratch [ksplit][B*Ho*Wo][Cout] with out_cs = cout_store = Cout; the caller runs
 // conv_splitk_reduce afterwards (bias + activation happen there).
+// Returns < 0: refused; 0: launched; 1: launched AND the last round ran as tail pieces (the scratch alone does not say so: an unaligned
+// output or a pooled layer with cout_store % 4 != 0 drops the tail here).
 #if HP3D_W4_TIMING
 static void w4_timing_report(const ConvParams& p, hipStream_t s, const char* what) {
     unsigned long long h[8] = {};
@@ -690,6 +692,7 @@ int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
         const unsigned blocks = (unsigned)((total + 255) / 256);
         if (pool) HP3D_LAUNCH(wino4_tail_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
         else HP3D_LAUNCH(wino4_tail_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+        return 1;
     }
     return 0;
 }

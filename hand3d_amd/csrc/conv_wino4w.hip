@@ -477,6 +477,7 @@ int conv_wino4w_launch(const ConvParams& pin, int pool, hipStream_t s) {
         const unsigned blocks = (unsigned)((total + 255) / 256);
         if (pool) HP3D_LAUNCH(ww_tail_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, p);
         else HP3D_LAUNCH(ww_tail_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, p);
+        return 1;                        // (as conv_wino4_launch: 1 = the last round ran as tail pieces)
     }
     return 0;
 }

@@ -242,7 +242,7 @@ struct hp3d_ctx {
     float *d_image = nullptr, *d_hs = nullptr, *d_large = nullptr, *d_crop = nullptr, *d_center = nullptr,
           *d_scale = nullptr, *d_cropsize = nullptr, *d_kpmap = nullptr, *d_coord = nullptr, *d_mask = nullptr,
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
-          *d_rot = nullptr, *d_u = nullptr, *d_fcin = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
+          *d_rot = nullptr, *d_u = nullptr, *d_fc1 = nullptr, *d_fc2 = nullptr, *d_fg = nullptr,
           *d_pooled = nullptr, *d_fcpart = nullptr;
     hipStream_t copy_stream = nullptr;   // hp3d_upload_async: H2D of the next batch under the current batch's kernels
     hipEvent_t upload_done = nullptr;
@@ -441,7 +441,6 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->d_can, (size_t)B * 63));
         CHK(dev_realloc(ctx, &ctx->d_rot, (size_t)B * 9));
         CHK(dev_realloc(ctx, &ctx->d_u, (size_t)B * 4));
-        CHK(dev_realloc(ctx, &ctx->d_fcin, (size_t)B * 4100));
         CHK(dev_realloc(ctx, &ctx->d_fc1, (size_t)B * 512));
         CHK(dev_realloc(ctx, &ctx->d_fc2, (size_t)B * 512));
         CHK(dev_realloc(ctx, &ctx->d_fcpart, (size_t)B * 17 * 512 + (size_t)B * 33 * 256));
@@ -609,7 +608,6 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                 ctx->col_floats = need;
             }
             p.partial = ctx->col; p.partial_cap = ctx->col_floats;
-            ++ctx->conv_wino4_tail_launches;
         }
         {
             const char* kn = take4 ? (l.k == 7 ? (wino2_ks > 1 ? "conv_wino4_f4x4_3x3_as7x7_splitk" : "conv_wino4_f4x4_3x3_as7x7")
@@ -618,9 +616,11 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                                     : (l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
                                                : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3");
             ProfScope ps(ctx, l.name, kn, flops, bytes);
-            if (wide ? conv_wino4w_launch(p, pool, ctx->stream)
-                     : take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream))
-                HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", take4 ? "F(4x4,3x3)" : "2 workgroups per CU");
+            // (the F(4x4,3x3) launchers answer 1 when the last round really ran as tail pieces: the counter below is the tests' proof)
+            const int lr = wide ? conv_wino4w_launch(p, pool, ctx->stream)
+                         : take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream);
+            if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", take4 ? "F(4x4,3x3)" : "2 workgroups per CU");
+            if (take4 && lr == 1) ++ctx->conv_wino4_tail_launches;
         }
         ++(take4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
         if (wide) ++ctx->conv_wino4w_launches;
@@ -850,10 +850,11 @@ int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
     return 0;
 }
 
-int run_fc(hp3d_ctx* ctx, const FcL& l, const float* x, int B, int x_stride, float* out, int out_stride) {
+// x2 != nullptr: the layer's last two inputs are the hand-side one-hot (concat(flatten, hand_side), :262-263 / :297-298, read in place)
+int run_fc(hp3d_ctx* ctx, const FcL& l, const float* x, int B, int x_stride, float* out, int out_stride, const float* x2 = nullptr) {
     ProfScope ps(ctx, l.name, "fc", 2.0 * l.cin * l.cout * B, 4.0 * ((double)l.cin * l.cout + (double)B * (l.cin + l.cout)));
     fc_launch(x, B, l.cin, x_stride, ctx->blob + l.w_off, ctx->blob + l.b_off, l.cout, l.relu, out, out_stride,
-              ctx->d_fcpart, ctx->stream);
+              ctx->d_fcpart, ctx->stream, x2, l.cin - 2);
     HIPCHK(ctx, hipGetLastError());
     return 0;
 }
@@ -875,8 +876,7 @@ int run_poseprior_can(hp3d_ctx* ctx, const float* sm32 /*[B,32,32,32]*/, const f
         x = b; cs = ch[i];   // next pair: b -> a -> b (no aliasing)
     }
     // x: [B,4,4,128] contiguous == NHWC flatten (h,w,c)
-    concat_handside_launch(x, B, 2048, hs, ctx->d_fcin, ctx->stream);
-    CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel0"), ctx->d_fcin, B, 2050, ctx->d_fc1, 512));
+    CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel0"), x, B, 2048, ctx->d_fc1, 512, hs));
     CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel1"), ctx->d_fc1, B, 512, ctx->d_fc2, 512));
     if (bottleneck) {
         CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_bottleneck"), ctx->d_fc2, B, 512, ctx->d_fc1, 32));
@@ -902,8 +902,7 @@ int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, floa
         CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
         x = b; cs = ch[i];   // next pair: b -> a -> b (no aliasing)
     }
-    concat_handside_launch(x, B, 4096, hs, ctx->d_fcin, ctx->stream);
-    CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp0"), ctx->d_fcin, B, 4098, ctx->d_fc1, 256));
+    CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp0"), x, B, 4096, ctx->d_fc1, 256, hs));
     CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp1"), ctx->d_fc1, B, 256, ctx->d_fc2, 128));
     CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp_u"), ctx->d_fc2, B, 128, u, 3));
     return 0;
@@ -1367,6 +1366,18 @@ int hp3d_device_count(int* count) {
 #endif
 }
 
+int hp3d_device_pci_bus_id(int device, char* buf, int cap) {
+    if (!buf || cap < 13) return HP3D_ERR_ARG;
+    buf[0] = 0;
+#ifdef HP3D_EMU
+    (void)device;
+    return HP3D_ERR_UNSUPPORTED;          // the CPU interpreter's one device sits on no bus
+#else
+    if (hipDeviceGetPCIBusId(buf, cap, device) != hipSuccess) { (void)hipGetLastError(); buf[0] = 0; return HP3D_ERR_HIP; }
+    return 0;
+#endif
+}
+
 int hp3d_create(int device, hp3d_ctx** out) {
     if (!out) return HP3D_ERR_ARG;
     *out = nullptr;
@@ -1408,7 +1419,7 @@ int hp3d_destroy(hp3d_ctx* ctx) {
     float** fp[] = {&ctx->blob, &ctx->bufA, &ctx->bufB, &ctx->col, &ctx->d_image, &ctx->d_hs, &ctx->d_large,
                     &ctx->d_crop, &ctx->d_center, &ctx->d_scale, &ctx->d_cropsize, &ctx->d_kpmap, &ctx->d_coord,
                     &ctx->d_mask, &ctx->d_segsmall, &ctx->d_concat, &ctx->d_sm[0], &ctx->d_sm[1], &ctx->d_sm[2],
-                    &ctx->d_can, &ctx->d_rot, &ctx->d_u, &ctx->d_fcin, &ctx->d_fc1, &ctx->d_fc2, &ctx->d_fg,
+                    &ctx->d_can, &ctx->d_rot, &ctx->d_u, &ctx->d_fc1, &ctx->d_fc2, &ctx->d_fg,
                     &ctx->d_pooled, &ctx->d_fcpart};
     for (float** p : fp)
         if (*p) hipFree(*p);
@@ -2031,11 +2042,11 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
                    (opw ? conv_wino4w_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) : conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr)) > 0) {
             p.partial = S.alloc<float>(conv_wino4_tail_floats()); NN(ctx, p.partial);         // tail pieces (conv_wino4.hip, TAIL)
             p.partial_cap = conv_wino4_tail_floats();
-            ++ctx->conv_wino4_tail_launches;
         }
-        if (opw ? conv_wino4w_launch(p, pool, ctx->stream)
-                : op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream))
-            HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
+        const int lr = opw ? conv_wino4w_launch(p, pool, ctx->stream)
+                     : op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream);
+        if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
+        if (op4 && lr == 1) ++ctx->conv_wino4_tail_launches;
         ++(op4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
         if (opw) ++ctx->conv_wino4w_launches;
         if (op_ks2 > 1 && pool)
@@ -2258,7 +2269,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n) {
         if (r.name.rfind("HandSegNet/", 0) == 0) st = 0;
         else if (r.name.rfind("PoseNet2D/", 0) == 0 || r.name == "kp_upsample") st = 2;
         else if (r.name.rfind("PosePrior", 0) == 0 || r.name.rfind("ViewpointNet/", 0) == 0 || r.name == "lift_epilogue" ||
-                 r.name == "concat_handside" || r.name.rfind("fc", 0) == 0) st = 3;
+                 r.name.rfind("fc", 0) == 0) st = 3;
         acc[st] += ms;
         acc[4] += ms;
     }

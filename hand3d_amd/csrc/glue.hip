@@ -547,34 +547,44 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
 //           workgroup, x slice staged transposed in LDS, W rows read coalesced (256 B per row).
 //   pass 2: out = act(bias + sum over K slices in index order).
 constexpr int FC_KCH = 128, FC_BT = 32;
+// x = [x | x2]: columns 0..F1-1 come from x (row stride x_stride), columns F1..Cin-1 from x2 (row stride Cin - F1) -- the
+// concat([flatten, hand_side]) of nets/ColorHandPose3DNetwork.py:262-263,297-298 without a copy (x2 = nullptr, F1 = Cin: plain).
+// The thread's 32 weights are all requested BEFORE the first multiply-add (round 5: the loop used to load one weight per
+// iteration behind a data-dependent exit, 32 dependent HBM / L2 round trips per workgroup = 12-25 us per launch for a few
+// MFLOP; the sums are the same, in the same order: rows beyond Cin contribute fmaf(0, 0, acc) = acc).
 HP3D_KERNEL(256)
-void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float* w, int Cout, float* part) {
+void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float* x2, int F1, const float* w, int Cout, float* part) {
     __shared__ float xs[FC_KCH][FC_BT + 4];        // [k][b], pitch 36 floats (16-B aligned rows)
     __shared__ float red[4][FC_BT][64];
     const int o = blockIdx.x * 64 + (threadIdx.x & 63);
     const int kq = threadIdx.x >> 6;               // K quarter: rows kq*32 .. kq*32+31 of the slice
     const int k0 = blockIdx.y * FC_KCH;
     const int b0 = blockIdx.z * FC_BT;
+    float wv[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+        const int gk = k0 + kq * 32 + u;
+        wv[u] = (o < Cout && gk < Cin) ? w[(size_t)gk * Cout + o] : 0.f;
+    }
     for (int i = threadIdx.x; i < FC_KCH * FC_BT; i += 256) {
         const int b = i / FC_KCH, kk = i - b * FC_KCH;       // coalesced along k
         const int gb = b0 + b, gk = k0 + kk;
-        xs[kk][b] = (gb < B && gk < Cin) ? x[(size_t)gb * x_stride + gk] : 0.f;
+        float v = 0.f;
+        if (gb < B && gk < Cin) v = gk < F1 ? x[(size_t)gb * x_stride + gk] : x2[(size_t)gb * (Cin - F1) + (gk - F1)];
+        xs[kk][b] = v;
     }
     __syncthreads();
     float acc[FC_BT];
 #pragma unroll
     for (int j = 0; j < FC_BT; ++j) acc[j] = 0.f;
-    if (o < Cout) {
-        for (int kk = kq * 32; kk < kq * 32 + 32; ++kk) {
-            const int gk = k0 + kk;
-            if (gk >= Cin) break;
-            const float wv = w[(size_t)gk * Cout + o];
 #pragma unroll
-            for (int j4 = 0; j4 < FC_BT / 4; ++j4) {
-                const f32x4 xv = *(const f32x4*)&xs[kk][j4 * 4];
+    for (int u = 0; u < 32; ++u) {
+        const int kk = kq * 32 + u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[j4 * 4 + e] = fmaf(xv[e], wv, acc[j4 * 4 + e]);
-            }
+        for (int j4 = 0; j4 < FC_BT / 4; ++j4) {
+            const f32x4 xv = *(const f32x4*)&xs[kk][j4 * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j4 * 4 + e] = fmaf(xv[e], wv[u], acc[j4 * 4 + e]);
         }
     }
 #pragma unroll
@@ -600,17 +610,6 @@ void fc_reduce_kernel(const float* part, int nslices, int B, int Cout, const flo
         v += bias[o];
         if (act) v = leaky(v);
         out[(size_t)b * out_stride + o] = v;
-    }
-}
-
-// out[b] = concat(feat[b, 0:F], hand_side[b, 0:2])   (nets/ColorHandPose3DNetwork.py:262-263,297-298)
-HP3D_KERNEL(256)
-void concat_handside_kernel(const float* feat, int B, int F, const float* hand_side, float* out) {
-    const long total = (long)B * (F + 2);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % (F + 2));
-        const long b = i / (F + 2);
-        out[i] = (c < F) ? feat[b * F + c] : hand_side[b * 2 + (c - F)];
     }
 }
 
@@ -849,15 +848,12 @@ void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltm
 }
 size_t fc_scratch_floats(int B, int Cin, int Cout) { return (size_t)((Cin + FC_KCH - 1) / FC_KCH) * B * Cout; }
 void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout, int act,
-               float* out, int out_stride, float* scratch, hipStream_t s) {
+               float* out, int out_stride, float* scratch, hipStream_t s, const float* x2, int F1) {
     const int ns = (Cin + FC_KCH - 1) / FC_KCH;
     HP3D_LAUNCH(fc_partial_kernel, dim3((Cout + 63) / 64, ns, (B + FC_BT - 1) / FC_BT), dim3(256), 0, s, x, B, Cin,
-                x_stride, w, Cout, scratch);
+                x_stride, x2, x2 ? F1 : Cin, w, Cout, scratch);
     HP3D_LAUNCH(fc_reduce_kernel, dim3(grid_for((long)B * Cout)), dim3(256), 0, s, (const float*)scratch, ns, B, Cout,
                 bias, act, out, out_stride);
-}
-void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s) {
-    HP3D_LAUNCH(concat_handside_kernel, dim3(grid_for((long)B * (F + 2))), dim3(256), 0, s, feat, B, F, hand_side, out);
 }
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B, float* rot,
                           float* coord_rel, int do_flip_rot, hipStream_t s) {

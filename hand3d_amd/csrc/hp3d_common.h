@@ -338,10 +338,9 @@ void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltm
                       float* center, float* crop_size, float* scale, int* seed, hipStream_t s);
 
 size_t fc_scratch_floats(int B, int Cin, int Cout);   // split-K partials [ceil(Cin/128)][B][Cout]
+// x2 / F1: input columns F1 .. Cin-1 come from x2 (row stride Cin - F1): concat([flatten, hand_side]) without a copy; nullptr = plain
 void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout,
-               int act, float* out, int out_stride, float* scratch, hipStream_t s);
-// [B,4096|2048 feats] + hand_side concat is handled by the executor (copies 2 floats per row)
-void concat_handside_launch(const float* feat, int B, int F, const float* hand_side, float* out, hipStream_t s);
+               int act, float* out, int out_stride, float* scratch, hipStream_t s, const float* x2 = nullptr, int F1 = 0);
 // u = (ux,uy,uz) [B,3], coord_can [B,63], hand_side [B,2] -> rot [B,9], coord_rel [B,63]
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B,
                           float* rot, float* coord_rel, int do_flip_rot, hipStream_t s);

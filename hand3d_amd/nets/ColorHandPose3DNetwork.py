@@ -53,8 +53,9 @@ def load_weight_files(engine, weight_files, exclude_var_list=None, verbose=True)
 
 
 def save_npz(weight_dict, npz_path):
-    """dict[tf variable name -> ndarray] -> one uncompressed .npz with the same keys (float32, C order)."""
-    np.savez(npz_path, **{k: np.ascontiguousarray(v, dtype=np.float32) for k, v in weight_dict.items()})
+    """dict[tf variable name -> ndarray] -> one uncompressed .npz with the same keys (C order, the arrays' own dtype: the
+    reference's pickles hold float32, and nothing here narrows a file that holds something else)."""
+    np.savez(npz_path, **{k: np.ascontiguousarray(v) for k, v in weight_dict.items()})
 
 
 def pickle_to_npz(weight_files, npz_path, exclude_var_list=None):
@@ -70,10 +71,14 @@ def pickle_to_npz(weight_files, npz_path, exclude_var_list=None):
 class ColorHandPose3DNetwork(object):
     """ Network performing 3D pose estimation of a human hand from a single color image. """
 
-    def __init__(self, device=0, engine=None):
+    def __init__(self, device=0, engine=None, keep_weights=False):
+        """`keep_weights=True` keeps a host reference to every array `init` assigns, for `export_npz` (off by default: the engine
+        owns a packed device copy, a second 140 MB host copy for the lifetime of the object serves nothing else;
+        `pickle_to_npz` converts files without a network object)."""
         self.crop_size = 256
         self.num_kp = 21
         self.engine = engine if engine is not None else Engine(device)
+        self.keep_weights = bool(keep_weights)
         self.weight_dict = dict()
 
     def init(self, session=None, weight_files=None, exclude_var_list=None):
@@ -81,17 +86,22 @@ class ColorHandPose3DNetwork(object):
             `session` is accepted for call compatibility and ignored. """
         if weight_files is None:
             weight_files = ['./weights/handsegnet-rhd.pickle', './weights/posenet3d-rhd-stb-slr-finetuned.pickle']
-        self.weight_dict.update(load_weight_files(self.engine, weight_files, exclude_var_list))
+        loaded = load_weight_files(self.engine, weight_files, exclude_var_list)
+        if self.keep_weights:
+            self.weight_dict.update(loaded)
 
     def init_from_dict(self, weight_dict, dtype=0):
         """Convenience for synthetic weights: the merged content of the weight files.
         dtype='f16' selects the half-precision trunks (BASELINE config 5)."""
         self.engine.load_weight_dict(weight_dict)
         self.engine.finalize_weights(dtype)
-        self.weight_dict.update(weight_dict)
+        if self.keep_weights:
+            self.weight_dict.update(weight_dict)
 
     def export_npz(self, npz_path):
-        """ Writes every variable assigned so far into one `.npz` (keys = TF variable names) that `init` reads back. """
+        """ Writes every variable assigned so far into one `.npz` (keys = TF variable names) that `init` reads back.
+            Needs `keep_weights=True` at construction (or use `pickle_to_npz` on the files). """
+        assert self.keep_weights, "export_npz needs ColorHandPose3DNetwork(keep_weights=True) (or use pickle_to_npz on the weight files)"
         save_npz(self.weight_dict, npz_path)
 
     @staticmethod

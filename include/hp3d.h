@@ -51,6 +51,11 @@ int hp3d_abi_version(void);
  * device TensorFlow picks, run.py:44-50): a launcher uses it to refuse `--gpus N` on a box with fewer devices BEFORE any rank
  * starts, instead of leaving N - n ranks to fail one by one inside a rendezvous.  Returns 0 or HP3D_ERR_HIP (then *count = 0). */
 int hp3d_device_count(int* count);
+/* PCI address "dddd:bb:dd.f" of HIP device `device` (hipDeviceGetPCIBusId) into buf (cap >= 13); needs no context.  No reference
+ * counterpart (same single-session script): a multi-rank launcher reads the device's NUMA node from
+ * /sys/bus/pci/devices/<address>/numa_node and pins the rank's host threads next to its GPU (bench.py: pin_to_gpu_numa).
+ * Returns 0, HP3D_ERR_HIP, or HP3D_ERR_UNSUPPORTED in the CPU interpreter build. */
+int hp3d_device_pci_bus_id(int device, char* buf, int cap);
 
 /* ---- context ----------------------------------------------------------------------------
  * replaces: tf.Session(config=...) + graph construction (run.py:44-50).                     */
@@ -99,7 +104,8 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            except inside tail items cut at other channels (profiles/r04_wide_items.md);
  *          "wino4_tail"   = "1" (default) | "0": conv_wino4.hip deals its work items round-robin to one workgroup per CU; when the last
  *                            round is at most half full (HandSegNet's 40x40 layers at B = 32: 800 items on 256 CUs = 3.125 rounds) its
- *                            items run as channel slices -- one piece per CU, raw sums to a 33 MB scratch, added in slice order by a small
+ *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
+ *                            MI355X (the second-stream child context grows its own), added in slice order by a small
  *                            reduce launch (deterministic; the summation order differs from the unsplit item: float32 rounding);
  *          "lift_fused"   = "auto" (default) | "0" | "1": PosePrior + ViewpointNet + the lifting epilogue
  *                            (ColorHandPose3DNetwork.py:221-334) as ONE persistent launch with grid barriers (lift_fused.hip)

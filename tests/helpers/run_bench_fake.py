@@ -28,13 +28,19 @@ class FakeBuf(object):
         pass
 
 
+class FakeLib(object):
+    def hp3d_posenet2d_dev(self, *a):
+        time.sleep(0.001)
+        return 0
+
+
 class FakeEngine(object):
     log = []
 
     def __init__(self, device=0, path=None):
         if os.environ.get('HP3D_FAKE_DIE_RANK') == os.environ.get('RANK', '-'):
             raise RuntimeError('no HIP device visible (fake): rank %s dies before the rendezvous' % os.environ.get('RANK'))
-        self.device, self.h, self.lib = device, 1, None
+        self.device, self.h, self.lib = device, 1, FakeLib()
         self.rank = self.world = None
         self.prof = 0
 
@@ -66,6 +72,13 @@ class FakeEngine(object):
 
     def set_option(self, k, v):
         pass
+
+    def close(self):
+        pass
+
+    def handsegnet(self, image, want_small=False):
+        B, H, W, _ = image.shape
+        return np.zeros((B, H, W, 2), np.float32), np.zeros((B, H // 8, W // 8, 2), np.float32)
 
     def to_device(self, a):
         return FakeBuf(np.asarray(a).nbytes)

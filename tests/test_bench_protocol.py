@@ -78,6 +78,24 @@ def test_bench_protocol_single_process_plain():
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec['n_gpus'] == 1 and rec['host_path'] is not None
     assert 'comm_init' not in out.stderr            # no launcher -> no communicator
+    # BASELINE.json's other configurations ride on the same line (N = 1, full workload, float32), each with its own timed region
+    oc = rec['other_configs']
+    assert [c['config'] for c in oc] == ['C1', 'C2', 'C4-shard@240x320', 'C5-shard'], oc
+    for c in oc:
+        assert 'error' not in c, c
+        assert c['images_per_s'] > 0 and c['ms_per_step'] > 0 and c['dominant_family'] == 'conv_wino'
+        assert c['parity_spot'] is None              # --cpu-seconds 0: no oracle leg, no spot check
+    assert (oc[0]['batch'], oc[0]['height'], oc[0]['width']) == (1, 240, 320) and (oc[3]['batch'], oc[3]['height'], oc[3]['dtype']) == (128, 480, 'f16')
+    assert rec['config']['cpu_affinity'] is None    # pinning is for launched ranks only
+
+
+def test_bench_other_configs_can_be_switched_off():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, HELPER, '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16', '--width', '16',
+                          '--cpu-seconds', '0', '--no-other-configs', '--no-host-path'], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert 'other_configs' not in rec and rec['host_path'] is None
 
 
 def test_bench_self_launch_spawns_the_ranks():
@@ -115,6 +133,23 @@ def test_bench_refuses_a_world_size_that_is_not_gpus():
     out = subprocess.run([sys.executable, HELPER, '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '2', '--height', '16',
                           '--width', '16'], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 2 and 'WORLD_SIZE' in out.stderr and out.stdout.strip() == ''
+
+
+def test_bench_launched_ranks_with_one_visible_device_each():
+    """Per-rank HIP_VISIBLE_DEVICES isolation (or one rank per node): every rank sees ONE device and has LOCAL_RANK 0 while WORLD_SIZE
+    is 2.  The device check of a launched rank is LOCAL_RANK < visible devices, not WORLD_SIZE <= visible devices."""
+    world, port = 2, _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HP3D_FAKE_DEVICES='1')
+        procs.append(subprocess.Popen([sys.executable, HELPER, '--gpus', str(world), '--steps', '2', '--warmup', '1', '--batch', '2',
+                                       '--height', '16', '--width', '16'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    rec = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert rec['n_gpus'] == world and rec['config']['rccl_ranks'] == world and 'other_configs' not in rec
 
 
 @pytest.mark.parametrize('launched', [False, True])

@@ -60,7 +60,12 @@ def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
     from hand3d_amd import Engine
     from hand3d_amd.nets.ColorHandPose3DNetwork import pickle_to_npz, read_weight_file
     paths = synth.write_weight_files(str(tmp_path), synth_weights)
-    net = ColorHandPose3DNetwork(engine=emu_engine)
+    lean = ColorHandPose3DNetwork(engine=emu_engine)
+    lean.init(None, weight_files=paths)
+    assert lean.weight_dict == {}, "weights are only retained on request"
+    with pytest.raises(AssertionError, match="keep_weights"):
+        lean.export_npz(str(tmp_path / 'no.npz'))
+    net = ColorHandPose3DNetwork(engine=emu_engine, keep_weights=True)
     net.init(None, weight_files=paths)
     npz = str(tmp_path / 'all.npz')
     net.export_npz(npz)

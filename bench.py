@@ -188,7 +188,7 @@ def families(rows):
     7x7 and 1x1 forms), conv_first (conv1_1), everything else under its own kernel name."""
     fam = {}
     for name, kern, ms, fl, by in rows:
-        k = ('conv_wino4' if kern.startswith('conv_wino4') else 'conv_wino2' if kern.startswith('conv_wino2') else
+        k = ('conv_wino4' if kern.startswith(('conv_wino4', 'conv_wino7')) else 'conv_wino2' if kern.startswith('conv_wino2') else
              'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
              'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
         # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
@@ -196,7 +196,9 @@ def families(rows):
         # (4*16 + 4*12 + 9) = 121 plane products per 4*49
         # conv_wino4 (F(4x4,3x3)): 36 products per 16 outputs = 36/144 of the direct form; a 7x7 filter as nine such blocks minus
         # their structurally zero planes: (4*36 + 4*30 + 25) = 289 plane products per 16*49
-        exe = ((289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
+        # conv_wino7 (F(4x4,4x4) over the 7x7 filter's four 4x4-tap blocks, round 5; counted in the conv_wino4 family = "Winograd with 4x4
+        # output tiles on the f32 matrix cores"): (49 + 42 + 42 + 36) = 169 plane products per 16*49
+        exe = ((169.0 / 784.0 if kern.startswith('conv_wino7') else 289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
                (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k in ('conv_wino', 'conv_wino2') else 1.0)
         f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
         f[0] += ms; f[1] += fl; f[2] += by; f[3] += 1; f[4] += fl * exe
@@ -283,36 +285,17 @@ def measure_config(eng, tag, what, call_site, workload, B, H, W, steps, warmup, 
     return rec, out
 
 
-def other_configs(eng, weights, a, device):
+def other_configs_measure(eng, weights, a, device):
     """BASELINE.json's OTHER configurations from the command the driver runs: C1 (run.py's call, B = 1 at
     240x320), C2 (eval2d_gt_cropped.py's PoseNet2D-only call, B = 1), the C4 per-GPU shard at eval_full.py's input size (B = 32 at
     240x320), and C5's per-GPU shape (B = 128 at 480x640, half-precision trunks; on a second context of the same device).  Each
     entry: images/s and ms/step of its own timed region, the dominant conv family with its executed fraction of the dense
-    matrix-core peak (separate event-timed pass), and a ONE-image parity spot check -- float32: the strict oracle on image 0
-    (heat-maps 1e-3, 3-D keypoints 1e-4); C5: the committed oracle fixture's segmentation logits (2e-3,
-    tests/test_gpu_c5_fixture.py's gate).  The oracle is the checker here, never the thing timed."""
+    matrix-core peak (separate event-timed pass).  GPU work only: this leg runs BEFORE the cpu_baseline / oracle leg, because a
+    torch-CPU region leaves its OpenMP threads spinning on the cgroup's cores for a while afterwards and the B = 1 configurations
+    are bound by how fast the host enqueues their ~60 launches (measured: C2 2.33 ms/step right behind an oracle call, 0.78 alone).
+    Returns (records, material for the parity spot checks)."""
     from hand3d_amd import Engine, synth
-    want_parity = a.cpu_seconds > 0
-    res = []
-
-    def spot(workload, img, hs, out):
-        if not want_parity:
-            return None
-        from oracle import nets as onets
-        from oracle import tf_ops as OT
-        OT.CONV_BACKEND = 'torch'
-        try:
-            if workload == 'full':
-                o = onets.inference(weights, img[0:1], hs[0:1], True)
-                return {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[4][0, ::8, ::8] - out['sm32'][0]).max()),
-                        "tolerance_heatmap": 1e-3, "max_abs_err_kp3d": float(np.abs(o[5][0] - out['coord3d'][0]).max()),
-                        "tolerance_kp3d": 1e-4, "against": "oracle/nets.py:inference (float64-accumulating restatement)"}
-            o = onets.posenet2d(weights, img[0:1])
-            return {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[2][0] - out['sm32'][0]).max()), "tolerance_heatmap": 1e-3,
-                    "against": "oracle/nets.py:posenet2d"}
-        finally:
-            OT.CONV_BACKEND = 'numpy'
-
+    res, keep = [], []
     plan = [
         ('C1', 'run.py forward pass shape: inference(), B=1, 240x320, f32', 'run.py:44-46', 'full', 1, 240, 320, 50, 10, 0),
         ('C2', 'PoseNet2D only on a ground-truth crop: inference_pose2d(), B=1, 256x256, f32', 'eval2d_gt_cropped.py:44-46', 'posenet', 1, 256, 256, 50, 10, 100),
@@ -323,8 +306,9 @@ def other_configs(eng, weights, a, device):
             img = synth.make_batch(seed, B, H, W)
             hs = synth.hand_sides(B)
             rec, out = measure_config(eng, tag, what, site, workload, B, H, W, steps, warmup, 'f32', img, hs)
-            rec["parity_spot"] = spot(workload, img, hs, out)
+            rec["parity_spot"] = None
             res.append(rec)
+            keep.append((rec, workload, img[0:1].copy(), hs[0:1].copy(), out))
         except Exception as e:            # one configuration failing must not take the primary line with it
             res.append({"config": tag, "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
     # ---- C5 per-GPU shape: half-precision trunks on a second context (own weights blob, own arena: ~25 GB of the 288 GB)
@@ -341,8 +325,9 @@ def other_configs(eng, weights, a, device):
         rec, _ = measure_config(eng16, 'C5-shard', "config 5's per-GPU shape: inference(), B=128, 480x640, f16 trunks (f32 accumulate, f32 heads / "
                                 "lifting / outputs)", 'run.py:44-46 at 480x640', 'full', B, H, W, 3, 1, 'f16', img, hs)
         rec["data"] = "16 distinct U(-0.5,0.5) frames (seeds 1000..1015) tiled to 128"
+        rec["parity_spot"] = None
         fix = os.path.join(ROOT, 'tests', 'golden', 'c5_f16_480x640.npz')
-        if want_parity and os.path.exists(fix):
+        if a.cpu_seconds > 0 and os.path.exists(fix):
             g = np.load(fix)
             n_img = int(g['seg_small'].shape[0])
             fimg = synth.make_batch(int(g['seed0']), n_img, H, W)
@@ -351,15 +336,38 @@ def other_configs(eng, weights, a, device):
             eng16.set_option('f16_impl', 'h16')
             rec["parity_spot"] = {"images": n_img, "max_abs_err_seg_logits": float(np.abs(small - g['seg_small']).max()), "tolerance": 2e-3,
                                   "against": "tests/golden/c5_f16_480x640.npz (oracle with the f16 rounding points, scripts/make_c5_fixture.py)"}
-        else:
-            rec["parity_spot"] = None
         res.append(rec)
     except Exception as e:
         res.append({"config": "C5-shard", "error": "%s: %s" % (type(e).__name__, str(e)[:300])})
     finally:
         if eng16 is not None:
             eng16.close()
-    return res
+    return res, keep
+
+
+def other_configs_parity(keep, weights):
+    """ONE-image parity spot check of each float32 configuration measured above: the strict oracle on image 0 (heat-maps 1e-3, 3-D
+    keypoints 1e-4).  (C5's check against the committed oracle fixture needs no CPU arithmetic and is done with its measurement.)
+    The oracle is the checker here, never the thing timed."""
+    from oracle import nets as onets
+    from oracle import tf_ops as OT
+    OT.CONV_BACKEND = 'torch'
+    try:
+        for rec, workload, img, hs, out in keep:
+            try:
+                if workload == 'full':
+                    o = onets.inference(weights, img, hs, True)
+                    rec["parity_spot"] = {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[4][0, ::8, ::8] - out['sm32'][0]).max()),
+                                          "tolerance_heatmap": 1e-3, "max_abs_err_kp3d": float(np.abs(o[5][0] - out['coord3d'][0]).max()),
+                                          "tolerance_kp3d": 1e-4, "against": "oracle/nets.py:inference (float64-accumulating restatement)"}
+                else:
+                    o = onets.posenet2d(weights, img)
+                    rec["parity_spot"] = {"image": 0, "max_abs_err_heatmap32": float(np.abs(o[2][0] - out['sm32'][0]).max()),
+                                          "tolerance_heatmap": 1e-3, "against": "oracle/nets.py:posenet2d"}
+            except Exception as e:
+                rec["parity_spot"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+    finally:
+        OT.CONV_BACKEND = 'numpy'
 
 
 def traffic_record(dom, workload_str, dtype):
@@ -622,9 +630,11 @@ def main():
             roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
                             "blocks without their structurally zero planes: 121/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
         if dom == 'conv_wino4':
-            roof["note"] = ("float32 Winograd F(4x4,3x3) (conv_wino4.hip): executes 36/144 of the direct-form multiply-adds (7x7 layers as nine "
-                            "3x3 blocks without their structurally zero planes: 289/784); frac is the executed matrix-core rate over the dense "
-                            "f32 MFMA peak, achieved_algorithmic the direct-form FLOPs over the same time")
+            roof["note"] = ("float32 Winograd with 4x4 output tiles: F(4x4,3x3) (conv_wino4.hip) executes 36/144 of the direct-form multiply-adds; "
+                            "the 7x7 layers run as F(4x4,4x4) over the filter's four 4x4-tap blocks (conv_wino7.hip, kernel conv_wino7_*: 169/784 "
+                            "after the structurally zero planes) where the launch fills the chip, else as nine 3x3 blocks on conv_wino4.hip "
+                            "(289/784); frac is the executed matrix-core rate over the dense f32 MFMA peak, achieved_algorithmic the "
+                            "direct-form FLOPs over the same time")
         workload_str = ("ColorHandPose3DNetwork.inference, %dx%dx3 f32 in HBM, %d images/GPU/step" % (H, W, B)) \
             if a.workload == 'full' else ("inference_pose2d, 256x256x3 f32 in HBM, %d images/GPU/step" % B)
         roof["traffic"], roof["traffic_source"] = traffic_record(dom, workload_str, a.dtype)
@@ -666,6 +676,14 @@ def main():
                                  "host per step; H2D of step n+1 overlapped with the kernels of step n; heat-maps stay on the device"}
             dev[1].free()
 
+        # BASELINE.json's other configurations: GPU measurements first (see other_configs_measure), their oracle spot checks after the CPU leg
+        oc = oc_keep = None
+        oc_wall = 0.0
+        if world == 1 and a.workload == 'full' and a.dtype == 'f32' and not a.no_other_configs:
+            t_oc = time.perf_counter()
+            oc, oc_keep = other_configs_measure(eng, weights, a, local)
+            oc_wall = time.perf_counter() - t_oc
+
         cpu = parity = None
         if world == 1 and a.cpu_seconds > 0:
             gpu_out = {'coord3d': eng.to_host(d_coord, (B, 21, 3)) if a.workload == 'full' else None}
@@ -698,10 +716,13 @@ def main():
             "roofline": roof, "roofline_other_conv": others, "cpu_baseline": cpu, "epe_vs_oracle": parity,
             "host_path": host_path,
         }
-        if world == 1 and a.workload == 'full' and a.dtype == 'f32' and not a.no_other_configs:
-            t_oc = time.perf_counter()
-            res["other_configs"] = other_configs(eng, weights, a, local)
-            res["other_configs_wall_s"] = round(time.perf_counter() - t_oc, 1)
+        if oc is not None:
+            if a.cpu_seconds > 0:
+                t_oc = time.perf_counter()
+                other_configs_parity(oc_keep, weights)
+                oc_wall += time.perf_counter() - t_oc
+            res["other_configs"] = oc
+            res["other_configs_wall_s"] = round(oc_wall, 1)
         if a.graph:
             res["config"]["hipgraph_replays"] = eng.counter('graph_replays')
         os.write(json_fd, (json.dumps(res) + '\n').encode())

@@ -56,6 +56,7 @@ struct ConvL {
     size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
     size_t ww2_off = 0;    // the same filters in conv_wino2.hip's fragment order (two workgroups per CU), 0 = none
     size_t ww4_off = 0;    // F(4x4,3x3) filters U[36][...] in conv_wino4.hip's fragment order (trunk nets), 0 = none
+    size_t ww7_off = 0;    // 7x7 layers: F(4x4,4x4) filters of the four 4x4-tap blocks in conv_wino7.hip's order [chunk][169][Cout/16][q][n][e], 0 = none
     size_t raw_off = 0;    // lifting nets only: [Cout/64][cin4][tap][64] for lift_fused.hip (one contiguous weight stream per wave), 0 = none
     int cin4 = 0;
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
@@ -98,6 +99,10 @@ struct Tables {
             if (net == NET_SEG || net == NET_POSE) {
                 l.ww4_off = blob_floats;
                 blob_floats += wino4_packed_floats(k, l.cin_pad, l.cout_pad);
+                if (k == 7) {
+                    l.ww7_off = blob_floats;
+                    blob_floats += wino7_packed_floats(l.cin_pad, l.cout_pad);
+                }
             }
         }
         if (net == NET_PRIOR || net == NET_VP) {
@@ -286,8 +291,8 @@ struct hp3d_ctx {
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
     int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
-    int w4_wide = 0;           // conv_wino4w.hip: the wide-item form (16 tiles x 128 couts, 32-channel steps) for the 3x3 layers it takes (option "wino4_wide": 0 | 1 | 2 = force)
-    long conv_wino4w_launches = 0;
+    int use_wino7 = -1;        // conv_wino7.hip (the 7x7 layers as Winograd F(4x4,4x4)), option "wino7": -1 auto (launches that fill the chip), 0 never, 1 wherever eligible
+    long conv_wino7_launches = 0;
     long conv_wino4_tail_launches = 0;
     long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
@@ -568,6 +573,28 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     int wino_ks = 1, wino2_ks = 1;
     const int old_nt = (ctx->use_wino && !f16 && l.ww_off) ? conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool,
                                                                                  ctx->wino_splitk ? &wino_ks : nullptr) : 0;
+    // 7x7 layers (PoseNet2D's refinement units): Winograd F(4x4,4x4) over the filter's four 4x4-tap blocks when the launch fills the chip
+    // (one work item = a 4x4 tile block x 64 couts, no channel split: 160 of 256 CUs busy already beats the split nine-block form + its reduce)
+    long items7 = 0;
+    const bool take7 = ctx->use_wino && ctx->use_wino7 && !f16 && l.ww7_off && !pool && !ctx->conv_naive &&
+        conv_wino7_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, &items7) &&
+        (ctx->use_wino7 == 1 || items7 >= (long)hp3d_num_cus() * 5 / 8);
+    if (take7) {
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.ww7_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
+        ProfScope ps(ctx, l.name, "conv_wino7_f4x4_4x4_as7x7", flops, bytes);
+        if (conv_wino7_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,4x4)): launch refused");
+        ++ctx->conv_wino7_launches;
+        HIPCHK(ctx, hipGetLastError());
+        if (Ho_out) *Ho_out = Ho;
+        if (Wo_out) *Wo_out = Wo;
+        return 0;
+    }
     int wino4_ks = 1;
     const bool take4 = ctx->use_wino && ctx->use_wino4 && !f16 && l.ww4_off && !ctx->conv_naive &&
         conv_wino4_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino4_ks : nullptr) &&
@@ -579,9 +606,6 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live));
     if (take4 || take2) {
         if (take4) wino2_ks = wino4_ks;          // (the block below serves both kernels: same parameters, same split / reduce protocol)
-        // conv_wino4w.hip: the same arithmetic and packed filters with wide items, for the 3x3 layers with Cout % 128 == 0 that fill the chip unsplit
-        const bool wide = take4 && ctx->w4_wide && wino2_ks == 1 &&
-            conv_wino4w_eligible(ctx->w4_wide, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool);
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + (take4 ? l.ww4_off : l.ww2_off); p.bias = ctx->blob + l.b_off; p.out = out;
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
@@ -599,7 +623,7 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
             }
             p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
         } else if (take4 && l.k == 3 && ctx->w4_tail &&
-                   (wide ? conv_wino4w_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) : conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr)) > 0) {
+                   conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
             // an under-filled last round of items runs as channel slices, one piece per CU (conv_wino4.hip, TAIL): scratch for the raw sums
             const size_t need = conv_wino4_tail_floats();
             if (need > ctx->col_floats) {
@@ -612,18 +636,16 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         {
             const char* kn = take4 ? (l.k == 7 ? (wino2_ks > 1 ? "conv_wino4_f4x4_3x3_as7x7_splitk" : "conv_wino4_f4x4_3x3_as7x7")
                                                : wino2_ks > 1 ? "conv_wino4_f4x4_3x3_splitk"
-                                               : wide ? (pool ? "conv_wino4w_f4x4_3x3_pool" : "conv_wino4w_f4x4_3x3") : pool ? "conv_wino4_f4x4_3x3_pool" : "conv_wino4_f4x4_3x3")
+                                               : pool ? "conv_wino4_f4x4_3x3_pool" : "conv_wino4_f4x4_3x3")
                                     : (l.k == 7 ? (wino2_ks > 1 ? "conv_wino2_f2x2_3x3_as7x7_splitk" : "conv_wino2_f2x2_3x3_as7x7")
                                                : wino2_ks > 1 ? "conv_wino2_f2x2_3x3_splitk" : pool ? "conv_wino2_f2x2_3x3_pool" : "conv_wino2_f2x2_3x3");
             ProfScope ps(ctx, l.name, kn, flops, bytes);
             // (the F(4x4,3x3) launchers answer 1 when the last round really ran as tail pieces: the counter below is the tests' proof)
-            const int lr = wide ? conv_wino4w_launch(p, pool, ctx->stream)
-                         : take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream);
+            const int lr = take4 ? conv_wino4_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, wino2_ks > 1 ? 0 : pool, ctx->stream);
             if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", take4 ? "F(4x4,3x3)" : "2 workgroups per CU");
             if (take4 && lr == 1) ++ctx->conv_wino4_tail_launches;
         }
         ++(take4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
-        if (wide) ++ctx->conv_wino4w_launches;
         if (wino2_ks > 1) {
             ProfScope ps(ctx, l.name, pool ? "conv_splitk_reduce_pool" : "conv_splitk_reduce", 0.0, 4.0 * (wino2_ks + 1) * B * Ho * Wo * l.cout_pad);
             if (pool)
@@ -1169,7 +1191,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->w4_wide = ctx->w4_wide; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1542,12 +1564,12 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
-    if (k == "wino4_wide" && (v == "0" || v == "1" || v == "force")) { ctx->w4_wide = v == "0" ? 0 : v == "1" ? 1 : 2; ++ctx->graph_epoch; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
         return 0;
     }
+    if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
     if (k == "f16_k7k1" && (v == "0" || v == "1")) { ctx->h16_k7k1 = v == "1"; return 0; }
@@ -1679,6 +1701,7 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
                 wino_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww_off);
                 wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww2_off);
                 if (l.ww4_off) wino4_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww4_off);
+                if (l.ww7_off) wino7_pack_weights(w->data.data(), l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww7_off);
             }
         });
     }
@@ -2014,6 +2037,26 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
+    if (ctx->use_wino && ctx->use_wino7 == 1 && !ctx->conv_naive && k == 7 && !pool && Cout % 64 == 0 &&
+        conv_wino7_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, nullptr)) {
+        // option "wino7" = "1": the F(4x4,4x4) form of a 7x7 filter (conv_wino7.hip)
+        const size_t wn = wino7_packed_floats(l.cin_pad, l.cout_pad);
+        std::vector<float> pw(wn + l.cout_pad, 0.f);
+        wino7_pack_weights(w_hwio, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
+        for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
+        float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
+        ConvParams p;
+        p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + wn; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
+        if (conv_wino7_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,4x4)): launch refused");
+        ++ctx->conv_wino7_launches;
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
+        return finish_op(ctx);
+    }
     int op_ks = 1, op_ks2 = 1;
     const bool op4 = ctx->use_wino && ctx->use_wino4 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
         conv_wino4_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr);
@@ -2034,21 +2077,18 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.act = act; p.im2col = 0; p.ksplit = op_ks2; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0;
         p.nsub = k == 7 ? 9 : 1;
         float* d_part = nullptr;
-        const bool opw = op4 && ctx->w4_wide && op_ks2 == 1 && conv_wino4w_eligible(ctx->w4_wide, k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool);
         if (op_ks2 > 1) {
             d_part = S.alloc<float>((size_t)op_ks2 * B * Ho * Wo * Cout); NN(ctx, d_part);
             p.out = d_part;
         } else if (op4 && k == 3 && ctx->w4_tail &&
-                   (opw ? conv_wino4w_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) : conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr)) > 0) {
+                   conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
             p.partial = S.alloc<float>(conv_wino4_tail_floats()); NN(ctx, p.partial);         // tail pieces (conv_wino4.hip, TAIL)
             p.partial_cap = conv_wino4_tail_floats();
         }
-        const int lr = opw ? conv_wino4w_launch(p, pool, ctx->stream)
-                     : op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream);
+        const int lr = op4 ? conv_wino4_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream) : conv_wino2_launch(p, op_ks2 > 1 ? 0 : pool, ctx->stream);
         if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (%s): launch refused", op4 ? "F(4x4,3x3)" : "2 workgroups per CU");
         if (op4 && lr == 1) ++ctx->conv_wino4_tail_launches;
         ++(op4 ? ctx->conv_wino4_launches : ctx->conv_wino2_launches);
-        if (opw) ++ctx->conv_wino4w_launches;
         if (op_ks2 > 1 && pool)
             conv_splitk_reduce_pool_launch(d_part, op_ks2, B, Ho, Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
         else if (op_ks2 > 1)
@@ -2252,7 +2292,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }
-    if (k == "conv_wino4w_launches") { *value = ctx->conv_wino4w_launches + (ctx->kid ? ctx->kid->conv_wino4w_launches : 0); return 0; }
+    if (k == "conv_wino7_launches") { *value = ctx->conv_wino7_launches + (ctx->kid ? ctx->kid->conv_wino7_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }

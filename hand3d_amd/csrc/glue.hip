@@ -3,6 +3,7 @@
 // expressions op by op in float32 (TF 1.3 CPU/GPU kernels), and the box / interpolation
 // arithmetic feeds discontinuous decisions (row validity, floor/ceil), so no FMA contraction.
 #include "hp3d_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -40,19 +41,47 @@ void conv_naive_kernel(const float* x, int B, int H, int W, int Cin, int in_cs, 
     }
 }
 
-// split-K epilogue of conv_mfma: fixed-order sum over the K slices, then bias + leaky-ReLU
+// split-K epilogue of conv_mfma / the Winograd kernels: fixed-order sum over the K slices, then bias + leaky-ReLU.
+// VEC = 4: a thread owns four consecutive couts (16-byte loads / stores; Cout, out_cs, cout_store multiples of 4, aligned pointers).
+// Up to eight slices are requested before the first addition (same order of additions): one load per addition is a chain of
+// `ksplit` dependent memory round trips -- 10 us for a 16-way split of a few hundred KB, which is what 25 of PoseNet2D's 56 launches
+// at B = 1 were (round 5).
+template <int VEC>
 HP3D_KERNEL(256)
 void conv_splitk_reduce_kernel(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
                                float* out, int out_cs, int cout_store) {
-    const long total = npix * cout_store;
+    typedef typename std::conditional<VEC == 4, f32x4, float>::type vec_t;
+    const int cvec = cout_store / VEC;
+    const long total = npix * cvec;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int co = (int)(i % cout_store);
-        const long pix = i / cout_store;
-        float v = 0.f;
-        for (int z = 0; z < ksplit; ++z) v += partial[((size_t)z * npix + pix) * Cout + co];
-        v += bias[co];
-        if (act) v = leaky(v);
-        out[pix * out_cs + co] = v;
+        const int co = (int)(i % cvec) * VEC;
+        const long pix = i / cvec;
+        const float* src = partial + (size_t)pix * Cout + co;
+        const size_t zs = (size_t)npix * Cout;
+        vec_t v = {};
+        int z = 0;
+        for (; z + 8 <= ksplit; z += 8) {
+            vec_t t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *(const vec_t*)(src + (size_t)(z + u) * zs);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        if (z + 4 <= ksplit) {
+            vec_t t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] = *(const vec_t*)(src + (size_t)(z + u) * zs);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v += t[u];
+            z += 4;
+        }
+        for (; z < ksplit; ++z) v += *(const vec_t*)(src + (size_t)z * zs);
+        v += *(const vec_t*)(bias + co);
+        if (act) {
+            if constexpr (VEC == 4) { for (int j = 0; j < 4; ++j) v[j] = leaky(v[j]); }
+            else v = leaky(v);
+        }
+        *(vec_t*)(out + pix * out_cs + co) = v;
     }
 }
 
@@ -605,8 +634,18 @@ void fc_reduce_kernel(const float* part, int nslices, int B, int Cout, const flo
     const int total = B * Cout;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int b = i / Cout, o = i - b * Cout;
+        // the slices are added in index order (deterministic); eight loads are in flight at a time -- one load per addition is a chain of
+        // nslices (17 / 33) dependent memory round trips, 12-23 us for a few KB (round 5)
         float v = 0.f;
-        for (int s = 0; s < nslices; ++s) v += part[((size_t)s * B + b) * Cout + o];
+        int s = 0;
+        for (; s + 8 <= nslices; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = part[((size_t)(s + u) * B + b) * Cout + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; s < nslices; ++s) v += part[((size_t)s * B + b) * Cout + o];
         v += bias[o];
         if (act) v = leaky(v);
         out[(size_t)b * out_stride + o] = v;
@@ -769,8 +808,11 @@ void conv_naive_launch(const float* x, int B, int H, int W, int Cin, int in_cs, 
 }
 void conv_splitk_reduce_launch(const float* partial, int ksplit, long npix, int Cout, const float* bias, int act,
                                float* out, int out_cs, int cout_store, hipStream_t s) {
-    HP3D_LAUNCH(conv_splitk_reduce_kernel, dim3(grid_for(npix * cout_store)), dim3(256), 0, s, partial, ksplit, npix,
-                Cout, bias, act, out, out_cs, cout_store);
+    const bool v4 = !((Cout | out_cs | cout_store) & 3) && !(((uintptr_t)partial | (uintptr_t)bias | (uintptr_t)out) & 15);
+    if (v4) HP3D_LAUNCH(conv_splitk_reduce_kernel<4>, dim3(grid_for(npix * (cout_store / 4))), dim3(256), 0, s, partial, ksplit, npix,
+                        Cout, bias, act, out, out_cs, cout_store);
+    else HP3D_LAUNCH(conv_splitk_reduce_kernel<1>, dim3(grid_for(npix * cout_store)), dim3(256), 0, s, partial, ksplit, npix,
+                     Cout, bias, act, out, out_cs, cout_store);
 }
 void conv_splitk_reduce_pool_launch(const float* partial, int ksplit, int B, int H, int W, int Cout, const float* bias, int act,
                                     float* out, int out_cs, int cout_store, hipStream_t s) {

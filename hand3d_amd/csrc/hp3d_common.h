@@ -105,17 +105,20 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  "v_mfma_f32_16x16x4_f32 %1, %3, %4, 0"                                                              \
                  : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
                  : "v"(a0e), "v"(a1e), "v"(be))
-// conv_wino4w.hip's pair: ONE A fragment element (16 tiles), the B elements of the wave's two cout groups
-#define HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e)                                                            \
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, %0\n\t"                                                       \
-                 "v_mfma_f32_16x16x4_f32 %1, %2, %4, %1"                                                             \
-                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
-                 : "v"(ae), "v"(b0e), "v"(b1e))
-#define HP3D_MFMA16_PAIRB_FIRST(REG, acc0, acc1, ae, b0e, b1e)                                                      \
-    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %3, 0\n\t"                                                        \
-                 "v_mfma_f32_16x16x4_f32 %1, %2, %4, 0"                                                              \
-                 : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
-                 : "v"(ae), "v"(b0e), "v"(b1e))
+// conv_wino7.hip: two products on two accumulators (one k quad each) -- neither MFMA waits for its predecessor; accumulators pinned to AGPRs
+#define HP3D_MFMA16_X2(acc0, acc1, a0e, a1e, b0e, b1e)                                                              \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %1, %3, %5, %1"                                                             \
+                 : "+a"(acc0), "+a"(acc1)                                                                           \
+                 : "v"(a0e), "v"(a1e), "v"(b0e), "v"(b1e))
+// ... and the odd product at the end of a chunk: four dependent MFMAs on one accumulator
+#define HP3D_MFMA16_X1(acc, a4, b4)                                                                                 \
+    asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %5, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %0, %2, %6, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %0, %3, %7, %0\n\t"                                                       \
+                 "v_mfma_f32_16x16x4_f32 %0, %4, %8, %0"                                                             \
+                 : "+a"(acc)                                                                                        \
+                 : "v"((a4)[0]), "v"((a4)[1]), "v"((a4)[2]), "v"((a4)[3]), "v"((b4)[0]), "v"((b4)[1]), "v"((b4)[2]), "v"((b4)[3]))
 // the first step of an item: the accumulators start from the inline constant 0 (never skipped)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                                                         \
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %10, 0\n\t"                                                       \
@@ -137,6 +140,8 @@ static __device__ __forceinline__ int hp3d_opaque_sgpr(int uniform_value) {
     return s;
 }
 #define HP3D_OPAQUE_SGPR(x) hp3d_opaque_sgpr(x)
+// s += inc on the scalar unit, opaque to the optimiser (a running offset that must not be re-derived as base + i * stride for every i)
+#define HP3D_SADD(s, inc) asm volatile("s_add_u32 %0, %0, %1" : "+s"(s) : "s"(inc) : "scc")
 // in-launch hand-off between workgroups (cdna_hip_programming.md Guideline 16, R1 in its counter form): the producers store their
 // payload write-through (HP3D_BUFFER_STORE4_SC1) and drain it (vmcnt(0) in every wave, then a barrier), one lane takes a ticket
 // with a relaxed agent-scope atomic; the last arriver acquires at agent scope (one lane, then a barrier) before plain loads.
@@ -302,10 +307,12 @@ int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, in
 int conv_wino4_launch(const ConvParams& p, int pool, hipStream_t s);
 // scratch (floats) the tail pieces of any conv_wino4 launch can need: two 32-tile x 64-cout blocks of raw 4x4 outputs per CU
 size_t conv_wino4_tail_floats();
-// conv_wino4w.hip: the same Winograd form with wide items (16 tiles x 128 couts, 32-channel steps); same packed filters and tail scratch
-int conv_wino4w_eligible(int mode /* 1: when the launch fills the chip, 2: whenever the shape allows */, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool);
-int conv_wino4w_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
-int conv_wino4w_launch(const ConvParams& p, int pool, hipStream_t s);
+// conv_wino7.hip: the 7x7 layers as Winograd F(4x4,4x4) over the filter's four 4x4-tap blocks (49 planes, V shared by the blocks);
+// packed filters [chunk Cin/16][169 non-zero (block, plane) products][Cout/16][q][n][e]
+size_t wino7_packed_floats(int cin_pad, int cout_pad);
+void wino7_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
+int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items);
+int conv_wino7_launch(const ConvParams& p, hipStream_t s);
 // > 0: conv_wino4_launch would share the last round of this layer out as tail pieces (given the scratch); channel steps per workgroup
 int conv_wino4_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);

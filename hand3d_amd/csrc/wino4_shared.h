@@ -1,7 +1,8 @@
-// wino4_shared.h -- what conv_wino4.hip (items of 32 tiles x 64 couts, 16-channel steps) and conv_wino4w.hip (16 tiles x 128 couts, 32-channel
-// steps) have in common: the F(4x4,3x3) transforms, the order in which a step's 36 window loads are issued, the tile / item geometry and the
-// reduction of tail pieces, the latter two parameterised by the item shape.  Device code only; everything sits in an anonymous namespace (one copy
-// per kernel file).  Moving these here left both files' convolution kernels instruction-for-instruction unchanged (checked on the compiler's assembly).
+// wino4_shared.h -- the item-shape independent parts of conv_wino4.hip (items of 32 tiles x 64 couts, 16-channel steps): the F(4x4,3x3)
+// transforms, the order in which a step's 36 window loads are issued, the tile / item geometry and the reduction of tail pieces, the latter two
+// parameterised by the item shape.  (Split out in round 4 for a second item shape, conv_wino4w.hip: 16 tiles x 128 couts in 32-channel steps.  That
+// kernel passed the whole GPU suite in round 5 and was then REMOVED: -2 % at the bench shape on that visit against +0.8 % in round 4 -- no
+// reliable win for 480 lines; profiles/r05_tuning_notes.md.)  Device code only; everything sits in an anonymous namespace.
 #pragma once
 #include "hp3d_common.h"
 

@@ -97,11 +97,12 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            the all-direct-kernel run in a mask pixel -- never in the crop box or, beyond 1e-4, in a keypoint over 512
  *                            images, scripts/mask_flip_rate.py); "1" = wherever the shape allows (tests); "0" = never.  Float32
  *                            throughout; end to end it moves heat-maps by 5e-6 and 3-D keypoints by 3e-6;
- *          "wino4_wide"   = "0" (default) | "1" | "force": the Winograd F(4x4,3x3) layers with Cout % 128 == 0 run on conv_wino4w.hip (work items of
- *                            16 tiles x 128 couts in 32-channel steps: half the input-transform work per MFMA, twice the weight stream) where
- *                            that measured faster (Cin >= 256, launches of two rounds and more: -2..-6 % per layer, +0.8 % at the bench shape)
- *                            | whenever the shape allows (tests).  Same packed filters and accumulation order: bit-identical to conv_wino4.hip
- *                            except inside tail items cut at other channels (profiles/r04_wide_items.md);
+ *          "wino7"        = "auto" (default) | "0" | "1": PoseNet2D's ten 7x7 layers (ColorHandPose3DNetwork.py:206-215) as Winograd
+ *                            F(4x4,4x4) over the filter's four 4x4-tap blocks (conv_wino7.hip, round 5: 169 instead of 289 plane products per
+ *                            16 outputs, the transformed input shared by the four blocks, one work item = 16 tiles x 64 couts with no channel
+ *                            split) when the launch fills the chip (>= 160 work items: B >= 20 on the 32 x 32 score maps) | never (the
+ *                            nine-3x3-block form on conv_wino4.hip / conv_wino2.hip) | whenever the shape allows (tests).  Float32 throughout,
+ *                            the same rounding error as the nine-block form (profiles/r05_wino7_numerics.md);
  *          "wino4_tail"   = "1" (default) | "0": conv_wino4.hip deals its work items round-robin to one workgroup per CU; when the last
  *                            round is at most half full (HandSegNet's 40x40 layers at B = 32: 800 items on 256 CUs = 3.125 rounds) its
  *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
@@ -266,7 +267,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
  * layers that ran on conv_h16.hip (option "f16_impl"); "conv_wino2_launches" = float32 layers that ran on conv_wino2.hip (option
  * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4"),
  * "conv_wino4_tail_launches" = those of them whose last round ran as channel slices (option "wino4_tail");
- * "conv_wino4w_launches" = those of them that ran on conv_wino4w.hip (option "wino4_wide");
+ * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7");
  * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);

@@ -40,7 +40,7 @@ def gpu_engine():
     assert os.path.exists(_lib.DEFAULT_LIB), "libhp3d.so not built (python -m hand3d_amd.build)"
     e = _lib.Engine(0, path=_lib.DEFAULT_LIB)
     # test infrastructure only: HP3D_TEST_OPTIONS="key=value,key=value" applies hp3d_set_option to the suite's engine, so that a non-default
-    # kernel policy (e.g. wino4_wide=1) can be taken through the WHOLE GPU suite before it becomes the default
+    # kernel policy (round 5: wino4_wide=1, the since-removed wide-item kernel) can be taken through the WHOLE GPU suite before it becomes the default
     for kv in filter(None, os.environ.get('HP3D_TEST_OPTIONS', '').split(',')):
         e.set_option(*kv.split('=', 1))
     yield e

@@ -55,6 +55,7 @@ static inline int hp3d_num_cus() { return 3; }     // small on purpose: persiste
 #define HP3D_SCHED_GROUP(kind, n) ((void)0)
 #define HP3D_READFIRSTLANE(x) (x)
 #define HP3D_OPAQUE_SGPR(x) (x)
+#define HP3D_SADD(s, inc) ((s) += (inc))
 #define HP3D_WAIT_VMCNT0() ((void)0)
 // workgroups run one after another on the interpreter: the hand-off protocol reduces to its arithmetic
 #define HP3D_ACQUIRE_AGENT() ((void)0)
@@ -156,16 +157,14 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
         (acc0) = _z; (acc1) = _z;                                                     \
         HP3D_MFMA16_PAIR_UNLESS(REG, acc0, acc1, a0e, a1e, be, 0);                    \
     } while (0)
-#define HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e)                              \
+#define HP3D_MFMA16_X2(acc0, acc1, a0e, a1e, b0e, b1e)                                \
     do {                                                                              \
-        (acc0) = hp3d_emu_mfma_16x16x4((ae), (b0e), (acc0));                          \
-        (acc1) = hp3d_emu_mfma_16x16x4((ae), (b1e), (acc1));                          \
+        (acc0) = hp3d_emu_mfma_16x16x4((a0e), (b0e), (acc0));                         \
+        (acc1) = hp3d_emu_mfma_16x16x4((a1e), (b1e), (acc1));                         \
     } while (0)
-#define HP3D_MFMA16_PAIRB_FIRST(REG, acc0, acc1, ae, b0e, b1e)                        \
+#define HP3D_MFMA16_X1(acc, a4, b4)                                                   \
     do {                                                                              \
-        const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                        \
-        (acc0) = _z; (acc1) = _z;                                                     \
-        HP3D_MFMA16_PAIRB(REG, acc0, acc1, ae, b0e, b1e);                             \
+        for (int _e = 0; _e < 4; ++_e) (acc) = hp3d_emu_mfma_16x16x4((a4)[_e], (b4)[_e], (acc)); \
     } while (0)
 #define HP3D_MFMA16_PLANE_FIRST(REG, acc0, acc1, a0, a1, b4)                      \
     do {                                                                          \

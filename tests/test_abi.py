@@ -98,9 +98,9 @@ def test_fp_contraction_is_confined_to_the_winograd_f4x4_kernel(tmp_path):
     of them in the interpolation kernels -- i.e. the check would see a leaked flag."""
     from hand3d_amd import build as hb
     assert '-ffp-contract=off' in hb.FLAGS and not any('contract=fast' in f for f in hb.FLAGS)
-    # (conv_wino4w.hip is the same kernel with wide work items: same transforms, same reason)
-    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip', 'conv_wino4w.hip'}, "another file with its own floating-point flags: extend this test before adding it"
-    assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip'] and '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4w.hip']
+    # (conv_wino7.hip: the F(4x4,4x4) form of the 7x7 layers -- its transforms multiply by 2, 4, 5, 1/2 ... too, same reason)
+    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip', 'conv_wino7.hip'}, "another file with its own floating-point flags: extend this test before adding it"
+    assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip'] and '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino7.hip']
     pat = re.compile(r'seg_upsample_softmax|seg_softmax|mask_grow|crop_and_resize|resize_bilinear|preprocess_u8|kp_detect|argmax2d')
     fused = re.compile(r'v_(fma|fmac|mad|pk_fma)_f32')
 
@@ -131,12 +131,12 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_p
     """The miscompile of round 2 (profiles/r02_tuning_notes.md, "conv_wino"): when hipcc cannot prove a buffer load's scalar offset
     wave-uniform it wraps the load in a waterfall loop (v_readfirstlane ... s_and_saveexec ... s_cbranch_execnz), and one such build
     returned WRONG 7x7 results on the GPU while the CPU interpreter of the same source was right.  So the shipped code object is
-    disassembled: in every conv_wino / conv_wino2 / conv_wino4 / conv_wino4w / conv_h16 kernel (a) no s_cbranch_execnz sits within a few instructions of a buffer load
+    disassembled: in every conv_wino / conv_wino2 / conv_wino4 / conv_wino7 / conv_h16 kernel (a) no s_cbranch_execnz sits within a few instructions of a buffer load
     (no waterfall loop), and (b) no scratch access lies inside the MFMA phase of a step / chunk loop (a spilled accumulator or
     address there drains the weight ring and has produced the slow builds recorded in the tuning notes)."""
     kernels = _kernel_disassembly(tmp_path)
-    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[24]?w?_kernel|conv_h16_kernel', k)}
-    assert len(hot) >= 10 and any('conv_wino4w' in k for k in hot), sorted(kernels)[:20]
+    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[247]?_kernel|conv_h16_kernel', k)}
+    assert len(hot) >= 10 and any('conv_wino7' in k for k in hot), sorted(kernels)[:20]
     for name, ins in hot.items():
         ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]
         n_mfma = sum(o.startswith('v_mfma') for o in ops)

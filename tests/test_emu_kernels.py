@@ -102,6 +102,7 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     # ... and onto conv_wino4.hip (F(4x4,3x3)): the executor's packed 36-plane filters, pooled layers, ragged 4x4 tiles at 16 x 24 and
     # its pooled sizes, the 7x7 units with the concat-channel permutation
     emu_engine.set_option('wino4', '1')
+    emu_engine.set_option('wino7', '0')           # (the 7x7 units on the nine-block form here; their F(4x4,4x4) form follows)
     try:
         n0 = emu_engine.counter('conv_wino4_launches')
         _, small_4 = emu_engine.handsegnet(img, want_small=True)
@@ -109,23 +110,20 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
         assert emu_engine.counter('conv_wino4_launches') >= n0 + 30
     finally:
         emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino7', 'auto')
     assert np.abs(small_4 - rs).max() < 3e-5
     for a, b in zip(sms_4, ref):
         assert np.abs(a - b).max() < 3e-5
-    # ... and the 3x3 layers with Cout % 128 == 0 onto conv_wino4w.hip (wide items) through the executor: the same packed filters,
-    # in-place activations with channel strides, pooled layers
-    emu_engine.set_option('wino4', '1')
-    emu_engine.set_option('wino4_wide', 'force')
+    # ... and PoseNet2D's 7x7 refinement layers on conv_wino7.hip (F(4x4,4x4) over the filter's four 4x4-tap blocks): the executor's packed
+    # filters [chunk][169 products], the concat-channel permutation of conv6_1 / conv7_1 over the 160-channel concat buffer
+    emu_engine.set_option('wino7', '1')
     try:
-        n0 = emu_engine.counter('conv_wino4w_launches')
-        _, small_w4 = emu_engine.handsegnet(img, want_small=True)
-        sms_w4 = net.inference_pose2d(crop)
-        assert emu_engine.counter('conv_wino4w_launches') >= n0 + 20
+        n0 = emu_engine.counter('conv_wino7_launches')
+        sms_7 = net.inference_pose2d(crop)
+        assert emu_engine.counter('conv_wino7_launches') == n0 + 10
     finally:
-        emu_engine.set_option('wino4', 'auto')
-        emu_engine.set_option('wino4_wide', '0')
-    assert np.abs(small_w4 - rs).max() < 3e-5
-    for a, b in zip(sms_w4, ref):
+        emu_engine.set_option('wino7', 'auto')
+    for a, b in zip(sms_7, ref):
         assert np.abs(a - b).max() < 3e-5
     rng = np.random.default_rng(5)
     sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
@@ -345,6 +343,42 @@ def test_winograd_7x7_as_3x3_blocks_on_interpreter(emu_engine, case):
     assert not np.array_equal(y, ys), "the split-K variant did not run (different summation order expected)"
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16, 32, 64, 1), (2, 9, 11, 48, 64, 0), (1, 20, 24, 16, 128, 1), (5, 16, 16, 32, 64, 1), (1, 32, 32, 160, 128, 1),
+                                  (1, 13, 18, 32, 192, 1), (9, 8, 8, 16, 64, 1)], ids=lambda c: "B%d_%dx%d_%d-%d_a%d" % c)
+def test_winograd_f4x4_4x4_for_7x7_filters_on_interpreter(emu_engine, case):
+    """conv_wino7.hip (round 5): a 7x7 filter as the four 4x4-tap blocks of its zero-extended 8x8 form, Winograd F(4x4,4x4) each over the points
+    {0, +-1, +-2, 1/2, inf} -- 49 planes, the structurally zero planes of the edge blocks left out at compile time, the transformed input of a
+    4x4 tile block + halo (25 windows) shared by the four blocks, work item = 16 tiles x 64 couts.  One tile block with ragged edges, blocks
+    at the image border (zero padding 3), several images per launch and more items than the interpreter's CUs (the persistent loop), Cin up
+    to the 160-channel concat buffer, three cout blocks.  Against the float64 oracle, and no further from it than twice the nine-block
+    F(4x4,3x3) form of conv_wino4.hip on the same input."""
+    B, H, W, Cin, Cout, act = case
+    rng = np.random.default_rng(sum(case) + 7)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    emu_engine.set_option('wino7', '1')
+    try:
+        n0 = emu_engine.counter('conv_wino7_launches')
+        y = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+        assert emu_engine.counter('conv_wino7_launches') == n0 + 1
+        assert np.array_equal(y, emu_engine.conv2d(x, w, b, 1, bool(act), False)), "not deterministic"
+    finally:
+        emu_engine.set_option('wino7', 'auto')
+    emu_engine.set_option('wino4', '1')
+    emu_engine.set_option('wino_splitk', '0')
+    try:
+        y9 = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+    e7, e9 = np.abs(y - r).max(), np.abs(y9 - r).max()
+    assert y.shape == r.shape and e7 < 1e-4 and e7 < 2 * e9 + 1e-5, (e7, e9)
+
+
 def _near_tie_scoremaps(trial, rng):
     """[2,32,32,21] score maps whose peak has a neighbour 1 ulp below it (an EARLIER interpolated position of the x8
     up-sampled map can then round up to the peak value) or an exact earlier tie."""
@@ -470,43 +504,6 @@ def test_winograd_f4x4_kernel_on_interpreter(emu_engine, case):
             assert np.abs(y - r).max() < 1e-4, (sk, np.abs(y - r).max())
     finally:
         emu_engine.set_option('wino4', 'auto')
-        emu_engine.set_option('wino_splitk', '1')
-
-
-@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 8, 8, 64, 128, 1), (1, 7, 9, 128, 128, 0), (1, 8, 12, 96, 256, 1), (1, 17, 21, 32, 128, 0),
-                                  # 8 tile blocks of 16 (the XCD-affine order), a single 32-channel step per item, three cout blocks, a pooled layer with an odd pooled extent
-                                  (2, 32, 32, 32, 128, 0), (1, 20, 24, 64, 384, 0), (1, 18, 22, 32, 128, 1),
-                                  # tail pieces on the interpreter's 3 CUs: 4 items (one round + one), 5 (one round + two: a run crosses items), 2 (less than a round)
-                                  (1, 16, 16, 128, 512, 0), (1, 16, 16, 128, 512, 1), (5, 16, 16, 128, 128, 0), (5, 16, 16, 128, 128, 1), (2, 16, 16, 128, 128, 0)],
-                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
-def test_winograd_f4x4_wide_items_on_interpreter(emu_engine, case):
-    """conv_wino4w.hip (option wino4_wide = force, round 4): the F(4x4,3x3) kernel with items of 16 tiles x 128 couts in 32-channel steps --
-    loader thread = (tile, channel pair of 32), V rows of eight swizzled quads, two B fragments per k quad from the UNCHANGED packed
-    filters (16-channel steps 2 s + h), eight MFMA pairs per plane, epilogue over two cout groups, tail pieces with this item shape.
-    Against the float64 oracle, and against conv_wino4.hip on the same input: the same products, another summation order."""
-    B, H, W, Cin, Cout, pool = case
-    rng = np.random.default_rng(sum(case) + 23)
-    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
-    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
-    b = rng.standard_normal(Cout).astype(np.float32)
-    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
-    if pool:
-        r = T.max_pool_2x2(r)
-    emu_engine.set_option('wino4', '1')
-    emu_engine.set_option('wino_splitk', '0')
-    try:
-        outs = {}
-        for wide in ('force', '0'):
-            emu_engine.set_option('wino4_wide', wide)
-            n0, w0 = emu_engine.counter('conv_wino4_launches'), emu_engine.counter('conv_wino4w_launches')
-            outs[wide] = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
-            assert emu_engine.counter('conv_wino4_launches') == n0 + 1
-            assert emu_engine.counter('conv_wino4w_launches') == w0 + (1 if wide == 'force' else 0)
-            assert outs[wide].shape == r.shape and np.abs(outs[wide] - r).max() < 1e-4, (wide, np.abs(outs[wide] - r).max())
-        assert np.abs(outs['force'] - outs['0']).max() < 1e-4
-    finally:
-        emu_engine.set_option('wino4', 'auto')
-        emu_engine.set_option('wino4_wide', '0')
         emu_engine.set_option('wino_splitk', '1')
 
 

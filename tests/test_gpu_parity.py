@@ -212,71 +212,6 @@ def test_conv_winograd_f4x4_tail_pieces(gpu_engine, case):
     assert y.shape == r.shape and d.max() < 1e-4 and 0 < frac < (1.01 if B * H < 200 else 0.5) and np.abs(y - r).max() < 2e-4
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (1, 18, 22, 32, 128, 1), (1, 30, 40, 512, 512, 0), (10, 64, 64, 256, 256, 0), (32, 40, 40, 512, 512, 0),
-                                  (16, 80, 80, 128, 256, 1), (3, 62, 78, 128, 384, 0)],
-                         ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
-def test_conv_winograd_f4x4_wide_items(gpu_engine, case):
-    """conv_wino4w.hip (option wino4_wide, round 4; default off): Winograd F(4x4,3x3) with items of 16 tiles x 128 couts in 32-channel
-    steps, from the same packed filters as conv_wino4.hip.  Small ragged shapes, PoseNet2D's 30x40 maps, launches with tail pieces (a quarter
-    / an eighth of a round left), a pooled layer, three cout blocks.  Against conv_wino4.hip on the same input (the same products, another
-    summation order) and against conv_wino.hip (F(2x2,3x3), itself oracle-checked); deterministic; the counter proves which kernel ran."""
-    B, H, W, Cin, Cout, pool = case
-    rng = np.random.default_rng(sum(case) + 31)
-    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
-    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
-    b = rng.standard_normal(Cout).astype(np.float32)
-    gpu_engine.set_option('wino4', '1')
-    gpu_engine.set_option('wino_splitk', '0')
-    try:
-        gpu_engine.set_option('wino4_wide', 'force')
-        n0 = gpu_engine.counter('conv_wino4w_launches')
-        y = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
-        assert gpu_engine.counter('conv_wino4w_launches') == n0 + 1
-        assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, bool(pool))), "not deterministic"
-        gpu_engine.set_option('wino4_wide', '0')
-        y4 = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
-        assert gpu_engine.counter('conv_wino4w_launches') == n0 + 2
-    finally:
-        gpu_engine.set_option('wino4_wide', '0')
-        gpu_engine.set_option('wino_splitk', '1')
-        gpu_engine.set_option('wino4', '0')
-    gpu_engine.set_option('conv_impl', 'winograd')
-    try:
-        r = gpu_engine.conv2d(x, w, b, 1, True, bool(pool))
-    finally:
-        gpu_engine.set_option('conv_impl', 'mfma')
-        gpu_engine.set_option('wino4', 'auto')
-    print("wide items %s: vs conv_wino4 %.2e, vs F(2x2,3x3) %.2e" % (case, np.abs(y - y4).max(), np.abs(y - r).max()))
-    assert y.shape == r.shape and np.abs(y - y4).max() < 1e-4 and np.abs(y - r).max() < 2e-4
-
-
-def test_full_pipeline_batch32_wide_items(gpu_engine, synth_weights):
-    """The whole path at the bench shape (B = 32, 320x320) with option wino4_wide = 1: the 3x3 trunk layers with Cout % 128 == 0 run on
-    conv_wino4w.hip (counter), everything else as by default.  Held against the default run of the same engine: same hand side decisions,
-    centres and crop scales (at most two knife-edge images may differ, as in test_full_pipeline_batch32_winograd_active), 3-D keypoints
-    within the path's 1e-4 bar, heat-maps within 1e-3."""
-    from hand3d_amd import ColorHandPose3DNetwork
-    net = ColorHandPose3DNetwork(engine=gpu_engine)
-    net.init_from_dict(synth_weights)
-    img = synth.make_batch(77, 32, 320, 320)
-    hs = synth.hand_sides(32)
-    base = net.inference(img, hs, True)
-    gpu_engine.set_option('wino4_wide', '1')
-    try:
-        n0 = gpu_engine.counter('conv_wino4w_launches')
-        out = net.inference(img, hs, True)
-        nw = gpu_engine.counter('conv_wino4w_launches') - n0
-    finally:
-        gpu_engine.set_option('wino4_wide', '0')
-    assert nw >= 10, nw          # (the layers with Cin >= 256: 7 of HandSegNet's, 4 of PoseNet2D's)
-    same = [i for i in range(32) if np.array_equal(out[3][i], base[3][i]) and np.array_equal(out[2][i], base[2][i])]
-    assert len(same) >= 30, len(same)
-    e3 = np.abs(out[5][same] - base[5][same]).max()
-    em = np.abs(out[4][same] - base[4][same]).max()
-    print("wide items, whole path: %d conv_wino4w launches, %d / 32 images with the default's crop, 3-D %.2e, heat-maps %.2e" % (nw, len(same), e3, em))
-    assert e3 < 1e-4 and em < 1e-3
-
-
 W4_CASES = [(2, 16, 32, 64, 128, 0, 3), (1, 8, 8, 64, 64, 1, 3), (1, 7, 9, 128, 64, 0, 3), (1, 17, 21, 32, 64, 0, 3), (1, 30, 40, 512, 512, 0, 3),
             (1, 32, 32, 256, 256, 0, 3), (2, 60, 80, 128, 256, 1, 3), (3, 10, 6, 16, 64, 1, 3), (16, 64, 64, 256, 256, 0, 3), (16, 128, 128, 128, 128, 1, 3),
             (1, 32, 32, 160, 128, 0, 7), (4, 32, 32, 128, 128, 0, 7), (16, 32, 32, 128, 128, 0, 7), (2, 9, 11, 48, 64, 0, 7),
@@ -682,21 +617,23 @@ def test_full_pipeline_320x320_and_determinism(net, synth_weights):
 
 def test_full_pipeline_batch32_winograd_active(net, synth_weights):
     """The bench workload shape (B=32, 320x320): at this size the default policy puts every 3x3 / stride-1 trunk layer with
-    Cout % 64 == 0 and the ten 7x7 layers on conv_wino4.hip (Winograd F(4x4,3x3), the headline kernel) -- asserted by kernel name
+    Cout % 64 == 0 on conv_wino4.hip (Winograd F(4x4,3x3), the headline kernel) and the ten 7x7 layers on conv_wino7.hip (F(4x4,4x4) over
+    the filter's four 4x4-tap blocks, round 5; the nine-3x3-block form on conv_wino4.hip until round 4) -- asserted by kernel name
     and by the engine's launch counter, so a silent fall-back to another kernel fails here.  EVERY image of the batch is checked
     against the oracle (two of them against its float64-accumulating form, the rest against the float32 one), then the whole batch
     against the direct-kernel engine."""
     from hand3d_amd.utils.general import EvalUtil
     img = synth.make_batch(3000, 32, 320, 320)
     hs = synth.hand_sides(32)
-    c0 = net.engine.counter('conv_wino4_launches')
+    c0, c7 = net.engine.counter('conv_wino4_launches'), net.engine.counter('conv_wino7_launches')
     o = net.engine.infer_full(img, hs, want_mask=True)
-    assert net.engine.counter('conv_wino4_launches') - c0 >= 36, "the F(4x4,3x3) kernel did not take the trunk layers"
+    assert net.engine.counter('conv_wino4_launches') - c0 >= 26, "the F(4x4,3x3) kernel did not take the 3x3 trunk layers"
+    assert net.engine.counter('conv_wino7_launches') - c7 == 10, "the F(4x4,4x4) kernel did not take the ten 7x7 layers"
     net.engine.set_profiling(1)
     net.engine.infer_full(img, hs)
     prof = net.engine.profile()
     net.engine.set_profiling(0)
-    w4 = [n for n, k, _, _, _ in prof if k.startswith(('conv_wino4_', 'conv_wino4w_'))]          # (the wide-item form counts: same arithmetic, option wino4_wide)
+    w4 = [n for n, k, _, _, _ in prof if k.startswith(('conv_wino4_', 'conv_wino7_'))]          # (the 7x7 layers' F(4x4,4x4) form counts: the same family)
     assert len(w4) >= 36 and 'HandSegNet/conv3_2' in w4 and 'PoseNet2D/conv4_2' in w4 and 'PoseNet2D/conv6_3' in w4, sorted(set(k for _, k, _, _, _ in prof))
     assert not [k for _, k, _, _, _ in prof if k.startswith(('conv_wino_', 'conv_wino2_'))], "a trunk layer fell back to an F(2x2,3x3) kernel"
     ev = EvalUtil()
@@ -1139,6 +1076,40 @@ def test_conv7x7_on_winograd_kernel_vs_oracle(gpu_engine, case):
     finally:
         gpu_engine.set_option('conv_impl', 'mfma')
     assert np.abs(y - r).max() < 5e-5
+
+
+@pytest.mark.parametrize("case", [(32, 32, 32, 128, 128), (4, 32, 32, 160, 128), (2, 30, 26, 64, 64), (1, 9, 11, 48, 64), (40, 32, 32, 149, 128), (3, 64, 48, 32, 192)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d" % c)
+def test_conv7x7_as_four_4x4_blocks_f4x4_vs_oracle(gpu_engine, case):
+    """conv_wino7.hip (round 5; PoseNet2D's ten 7x7 layers, nets/ColorHandPose3DNetwork.py:206-215): the 7x7 filter as the four 4x4-tap
+    blocks of its zero-extended 8x8 form, Winograd F(4x4,4x4) each (49 planes; 169 plane products per 16 outputs after the structurally
+    zero planes, 289 in the nine-3x3-block form), the transformed input of a tile block shared by the four blocks.  The bench shape's own
+    layer (32 x 32x32 x 128 -> 128: exactly 256 work items), the 160-channel concat buffer, ragged sizes with partial tile blocks, a
+    single small image, more items than CUs with the real first layer's 149 channels, three cout blocks on a non-square map.  Against the
+    float64 oracle; against the nine-block form on the same input (no further from the oracle than twice that form + 1e-5); deterministic;
+    the counter proves which kernel ran."""
+    B, H, W, Cin, Cout = case
+    rng = np.random.default_rng(sum(case) + 77)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    gpu_engine.set_option('wino7', '1')
+    try:
+        n0 = gpu_engine.counter('conv_wino7_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, False)
+        assert gpu_engine.counter('conv_wino7_launches') == n0 + 1
+        assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, False)), "not deterministic"
+    finally:
+        gpu_engine.set_option('wino7', 'auto')
+    gpu_engine.set_option('wino4', '1')
+    try:
+        y9 = gpu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        gpu_engine.set_option('wino4', 'auto')
+    e7, e9 = float(np.abs(y - r).max()), float(np.abs(y9 - r).max())
+    print("7x7 as four 4x4 blocks %s: F(4x4,4x4) %.2e from the float64 oracle, the nine-block F(4x4,3x3) form %.2e" % (case, e7, e9))
+    assert y.shape == r.shape and e7 < 1e-4 and e7 < 2 * e9 + 1e-5
 
 
 def test_device_keypoints_equal_reference_host_functions(net, synth_weights):

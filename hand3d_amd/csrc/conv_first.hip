@@ -158,8 +158,11 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
                 const int base = (oy < p.H && ox < p.W) ? (((b * p.H + oy) * p.W + ox) * p.out_cs + m) * 4 : OOR;
                 float v0 = acc0[r], v1 = acc1[r];
                 if (p.act) { v0 = fmaxf(v0, HP3D_LEAKY_SLOPE * v0); v1 = fmaxf(v1, HP3D_LEAKY_SLOPE * v1); }
-                HP3D_BUFFER_STORE4(orsrc, v0, base, 0);
-                HP3D_BUFFER_STORE4(orsrc, v1, base, 128);
+                // non-temporal stores (round 5): the 64-channel activation is written once and read back one layer later, after 0.5-0.8 GB
+                // have passed the 256 MB memory-side cache.  Measured at B = 32, 320x320: this layer 0.237 -> 0.251 ms (HandSegNet) and
+                // 0.157 -> 0.126 ms (PoseNet2D: 4.46 TB/s), the conv1_2 behind it 0.706 -> 0.686 and 0.458 -> 0.441: -0.05 ms per step
+                HP3D_BUFFER_STORE4_NT(orsrc, v0, base, 0);
+                HP3D_BUFFER_STORE4_NT(orsrc, v1, base, 128);
             }
         }
 #pragma unroll

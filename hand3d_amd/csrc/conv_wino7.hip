@@ -71,6 +71,22 @@ constexpr W7Seq w7_make_seq() {
     return s;
 }
 constexpr W7Seq W7_SEQ_TAB = w7_make_seq();
+// ISSUE ORDER of a chunk's 49 window loads.  Window element (r, c) of slot (hy, hx) is the pixel (4 hy + r - 3, 4 hx + c - 3): elements (r, c),
+// (r + 4, c), (r, c + 4), (r + 4, c + 4) of neighbouring slots are the SAME pixels, i.e. the same cache lines asked for by other lanes.  Issued
+// class by class ((r mod 4, c mod 4): 16 classes of 4 / 2 / 1 elements) the repeats follow each other within a group or two and hit the L1
+// line or its pending fill; in row-major order they lie four groups (1000 cycles, 40 KB of weight stream through the 32 KB L1) apart
+// (conv_wino4.hip's finding of round 4, same reason).
+struct W7Issue { int e[W7_NP]; };
+constexpr W7Issue w7_make_issue() {
+    W7Issue s{};
+    int n = 0;
+    for (int rc = 0; rc < 4; ++rc)
+        for (int cc = 0; cc < 4; ++cc)
+            for (int r = rc; r < 7; r += 4)
+                for (int c = cc; c < 7; c += 4) s.e[n++] = r * 7 + c;
+    return s;
+}
+constexpr W7Issue W7_ISSUE = w7_make_issue();
 static_assert(W7_SEQ_TAB.pl[W7_SEQ - 1] == 40 && W7_SEQ_TAB.blk[W7_SEQ - 1] == 3, "169 products: the last one is block (1,1), plane (5,5)");
 
 // B^T of F(4,4) over {0, 1, -1, 2, -2, 1/2, inf}, applied to seven values in place (rows printed by scripts/micro/wino_f44.py):
@@ -267,7 +283,7 @@ void conv_wino7_kernel(const ConvParams p) {
                         if (e == 0) { if (t0 + 2 < W7_SEQ) a_fetch(t0 + 2); }
                         else if (e == 1) { if (t1 + 2 < W7_SEQ) a_fetch(t1 + 2); }
                         else if (e == 2) {
-                            if (g < W7_NP) window_load(g, wsoff);                        // next chunk's windows: one per group over the first 49
+                            if (g < W7_NP) window_load(W7_ISSUE.e[g], wsoff);            // next chunk's windows: one per group over the first 49, class by class
                         } else {
                             b_fetch(t0);          // product t0 + 13 of the stream (this chunk's, or the next chunk's first ones) into the slot t0 released
                             b_fetch(t1);

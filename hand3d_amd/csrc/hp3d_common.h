@@ -193,6 +193,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 16 B per lane from (rsrc base + per-lane voff + scalar soff) straight into VGPRs
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) \
     __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 0))
+// the same with the non-temporal hint (nt): a stream that is read once and must not displace the lines other loads re-use
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) \
+    __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128((rsrc), (voff), (soff), 2))
 // 8 B per lane (same addressing / range check)
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) \
     __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64((rsrc), (voff), (soff), 0))
@@ -205,6 +208,9 @@ typedef __amdgpu_buffer_rsrc_t hp3d_rsrc_t;
 // 4 B per lane to (rsrc base + per-lane voff + scalar soff); out-of-range offsets are dropped by the hardware
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) \
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 0)
+// the same store with the non-temporal hint (nt)
+#define HP3D_BUFFER_STORE4_NT(rsrc, val, voff, soff) \
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (float)(val)), (rsrc), (voff), (soff), 2)
 // the same store written through to memory (sc1): payload of an in-launch hand-off to a workgroup on another XCD -- no
 // L2 write-back fence needed afterwards (cdna_hip_programming.md Guideline 16, R1)
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) \
@@ -223,9 +229,11 @@ typedef int hp3d_rsrc_t;
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) ((void)(rsrc), (void)(lds_wave_base), (void)(voff), (void)(soff), (void)(lane))
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_LOAD8(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x2{0.f, 0.f})
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) ((void)(rsrc), (void)(voff), (void)(soff), f32x4{0.f, 0.f, 0.f, 0.f})
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
+#define HP3D_BUFFER_STORE4_NT(rsrc, val, voff, soff) ((void)(rsrc), (void)(val), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16_SC1(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE16(rsrc, val4, voff, soff) ((void)(rsrc), (void)(val4), (void)(voff), (void)(soff))
 #define HP3D_BUFFER_STORE2(rsrc, half_val, voff, soff) ((void)(rsrc), (void)(half_val), (void)(voff), (void)(soff))

@@ -75,6 +75,7 @@ static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
     return v;
 }
 #define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 #define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
 static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     float v = 0.f;
@@ -92,6 +93,7 @@ static inline void hp3d_emu_buffer_store4(hp3d_rsrc_t r, float v, unsigned voff,
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 4);   // hardware: range check on voff
 }
 #define HP3D_BUFFER_STORE4(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_STORE4_NT(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
 #define HP3D_BUFFER_STORE4_SC1(rsrc, val, voff, soff) hp3d_emu_buffer_store4((rsrc), (val), (unsigned)(voff), (unsigned)(soff))
 static inline void hp3d_emu_buffer_store2(hp3d_rsrc_t r, hp3d_f16 v, unsigned voff, unsigned soff) {
     if (voff < r.bytes && voff + soff + 2u <= r.bytes) memcpy((char*)r.base + voff + soff, &v, 2);

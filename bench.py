@@ -178,19 +178,20 @@ def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s, alg_flop_per_imag
     return cpu, par
 
 
-CONV_FAMILIES = ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3')
+CONV_FAMILIES = ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3', 'conv_pw2')
 
 
 def families(rows):
     """Per-launch profile rows (name, kernel, ms, flops, bytes) -> {family: [ms, flops, bytes, launches, executed flops]}, total ms.
     Families: conv_wino / conv_wino2 (Winograd F(2x2,3x3) forms of the 3x3 / 7x7 layers), conv_wino4 (F(4x4,3x3), incl. the wide-item
     and 16-tile forms), conv_mfma (direct implicit GEMM), conv_h16 (half-precision trunk kernel incl. its pooled, fused-first-block,
-    7x7 and 1x1 forms), conv_first (conv1_1), everything else under its own kernel name."""
+    7x7 and 1x1 forms), conv_first (conv1_1), conv_pw2 (the 1x1 head pairs as one launch), everything else under its own kernel name."""
     fam = {}
     for name, kern, ms, fl, by in rows:
         k = ('conv_wino4' if kern.startswith(('conv_wino4', 'conv_wino7')) else 'conv_wino2' if kern.startswith('conv_wino2') else
              'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
-             'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else kern)
+             'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else
+             'conv_pw2' if kern.startswith('conv_pw2') else kern)
         # multiply-adds the matrix cores execute per direct-form multiply-add: Winograd F(2x2,3x3) 16/36; a 7x7 filter as
         # nine 3x3 blocks of its zero-extended 9x9 form, minus the structurally zero planes of the edge blocks (round 3):
         # (4*16 + 4*12 + 9) = 121 plane products per 4*49

@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhp3d.so')
-SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino7.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
+SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
 HEADERS = ['hp3d_common.h', 'lift_fused.h', 'wino4_shared.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']

@@ -442,6 +442,7 @@ void conv_wino4_kernel(const ConvParams p) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 #endif
         const int* tab = tinfo + (k & 1) * 2 * W4_TILES;
+        const float slope = p.act ? HP3D_LEAKY_SLOPE : 1.f;
         // every tile of the launch is a whole 4x4 block (pooled: 2x2) when the output extent is a multiple of 4 -- all trunk layers at the
         // network's own sizes: the per-store edge selects then fall away (tiles beyond the batch carry no offset and stay out of range)
         const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0 || raw) ? 1 : 0) != 0;
@@ -472,7 +473,7 @@ void conv_wino4_kernel(const ConvParams p) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float x = y[i][j] + bias;
-                            if (!SPLITK && p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                            if (!SPLITK) x = fmaxf(x, slope * x);           // (slope 1 = a linear layer: max(x, x); no per-value select on p.act)
                             y[i][j] = x;
                         }
                     }
@@ -487,7 +488,7 @@ void conv_wino4_kernel(const ConvParams p) {
                                 // bias + leaky-ReLU AFTER the max: x -> fl(x + bias) and the leaky-ReLU are monotonic, so
                                 // max_i act(fl(y_i + b)) == act(fl(max_i y_i + b)) bit for bit -- 4 instead of 16 per tile and cout
                                 float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
-                                if (p.act) v = fmaxf(v, HP3D_LEAKY_SLOPE * v);
+                                v = fmaxf(v, slope * v);
                                 const bool ok = FULL || ((pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2)));
                                 if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(v), "v"(ok ? vo : OOR));
                                 else HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);

@@ -322,6 +322,7 @@ void conv_wino7_kernel(const ConvParams p) {
         const int cout = cy * W7_COUTS + wave * 16 + ln;
         const float bias = p.bias[cout];
         const bool cok = cout < p.cout_store;
+        const float slope = p.act ? HP3D_LEAKY_SLOPE : 1.f;
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, out_bytes);
         const int srow = p.Wo * p.out_cs * 4, scol = p.out_cs * 4;
         const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0) ? 1 : 0) != 0;
@@ -343,7 +344,7 @@ void conv_wino7_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float x = y[i][j] + bias;
-                    if (p.act) x = fmaxf(x, HP3D_LEAKY_SLOPE * x);
+                    x = fmaxf(x, slope * x);                // (slope 1 = a linear layer)
                     y[i][j] = x;
                 }
             }

@@ -291,6 +291,9 @@ struct hp3d_ctx {
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
     int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
+    int use_pw2 = 1;           // conv_pw2.hip: the 1x1 head pairs (conv6_1 + conv6_2, conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7) as one launch each
+                               // (option "pw2": 0 never, 1 when the launch has a workgroup per CU, 2 = "force": whenever the shapes allow, tests)
+    long conv_pw2_launches = 0;
     int use_wino7 = -1;        // conv_wino7.hip (the 7x7 layers as Winograd F(4x4,4x4)), option "wino7": -1 auto (launches that fill the chip), 0 never, 1 wherever eligible
     long conv_wino7_launches = 0;
     long conv_wino4_tail_launches = 0;
@@ -760,6 +763,29 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
 const ConvL& CL(hp3d_ctx* ctx, const char* name) { return ctx->T.conv[ctx->T.conv_idx.at(name)]; }
 const FcL& FL(hp3d_ctx* ctx, const char* name) { return ctx->T.fc[ctx->T.fc_idx.at(name)]; }
 
+// Two 1x1 layers as one launch (conv_pw2.hip): l1 = 128 -> H (a multiple of 128), l2 = H -> at most 32 couts, float32 mode, enough pixels to fill
+// the chip (64 pixels per workgroup, two workgroups per CU).  Returns 1 if it ran, 0 if the shapes / options do not allow it (the caller
+// then runs the two layers one by one).
+int run_pw2(hp3d_ctx* ctx, const ConvL& l1, const ConvL& l2, const float* in, int in_cs, int B, int h, int w, float* out, int out_cs) {
+    const long npix = (long)B * h * w;
+    if (!ctx->use_pw2 || ctx->prec || ctx->conv_naive || l1.k != 1 || l2.k != 1 || l1.stride != 1 || l2.stride != 1 || l1.mode != 0 || l2.mode != 0 ||
+        l2.cin_pad != l1.cout_pad || (ctx->use_pw2 == 1 && npix < 64L * hp3d_num_cus()) ||
+        !conv_pw2_eligible(l1.cin_pad, l1.cout_pad, l2.cout_pad, npix, in_cs, out_cs) || (in_cs & 3) || ((uintptr_t)in & 15))
+        return 0;
+    Pw2Params p;
+    p.in = in; p.in_cs = in_cs; p.npix = npix;
+    p.w1 = ctx->blob + l1.w_off; p.b1 = ctx->blob + l1.b_off; p.H = l1.cout_pad; p.act1 = l1.relu;
+    p.w2 = ctx->blob + l2.w_off; p.b2 = ctx->blob + l2.b_off; p.act2 = l2.relu;
+    p.out = out; p.out_cs = out_cs; p.cout_store = std::min(l2.cout_pad, out_cs);
+    const double flops = 2.0 * npix * ((double)l1.cin * l1.cout + (double)l2.cin * l2.cout);
+    const double bytes = 4.0 * (npix * ((double)l1.cin + l2.cout) + (double)l1.cin * l1.cout + (double)l2.cin * l2.cout);
+    ProfScope ps(ctx, l1.name + "+" + l2.name.substr(l2.name.find('/') + 1), "conv_pw2_1x1_1x1", flops, bytes);
+    if (conv_pw2_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "conv_pw2: launch refused for %s", l1.name.c_str());
+    ++ctx->conv_pw2_launches;
+    HIPCHK(ctx, hipGetLastError());
+    return 1;
+}
+
 // Half-precision trunks: conv1_1 (3 -> 64) + conv1_2 (64 -> 64) + 2x2 max-pool as ONE launch of conv_h16.hip's fused form
 // (conv1_1's activation never reaches HBM).  Returns 1 if it ran, 0 if the shape / options do not allow it.
 int run_fused12(hp3d_ctx* ctx, const ConvL& l1, const ConvL& l2, const float* image, int B, int H, int W, float* out, int* oh, int* ow) {
@@ -824,6 +850,10 @@ int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W) {
     const int f16 = ctx->prec;
     CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_1"), a, 512, B, h, w, b, 512, 0, nullptr, nullptr, f16));
     CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_2"), b, 512, B, h, w, a, 128, 0, nullptr, nullptr, f16));
+    // conv6_1 (1x1, 128 -> 512) + conv6_2 (1x1, 512 -> 2): one launch where conv_pw2.hip takes the pair (the 512-channel map stays in LDS)
+    const int fused = run_pw2(ctx, CL(ctx, "HandSegNet/conv6_1"), CL(ctx, "HandSegNet/conv6_2"), a, 128, B, h, w, ctx->d_segsmall, 32);
+    if (fused < 0) return fused;
+    if (fused) return 0;
     CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_1"), a, 128, B, h, w, b, 512, 0, nullptr, nullptr, f16));
     // the 2-class head always leaves float32 logits for the softmax / mask stage
     CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv6_2"), b, 512, B, h, w, ctx->d_segsmall, 32, 0, nullptr, nullptr, f16, 1));
@@ -846,9 +876,15 @@ int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
     CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_5"), a, 256, B, h, w, b, 256, 0, nullptr, nullptr, f16));
     CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_6"), b, 256, B, h, w, a, 256, 0, nullptr, nullptr, f16));
     CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv4_7"), a, 256, B, h, w, cat, ccs, 0, nullptr, nullptr, f16));
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_1"), cat, ccs, B, h, w, a, 512, 0, nullptr, nullptr, f16));
     // score-map heads always store float32 [.,32] (they feed the lifting nets, the up-sampler and the caller)
-    CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_2"), a, 512, B, h, w, ctx->d_sm[0], 32, 0, nullptr, nullptr, f16, 1));
+    {
+        const int fused = f16 ? 0 : run_pw2(ctx, CL(ctx, "PoseNet2D/conv5_1"), CL(ctx, "PoseNet2D/conv5_2"), cat, ccs, B, h, w, ctx->d_sm[0], 32);
+        if (fused < 0) return fused;
+        if (!fused) {
+            CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_1"), cat, ccs, B, h, w, a, 512, 0, nullptr, nullptr, f16));
+            CHK(run_conv(ctx, CL(ctx, "PoseNet2D/conv5_2"), a, 512, B, h, w, ctx->d_sm[0], 32, 0, nullptr, nullptr, f16, 1));
+        }
+    }
     char nm[64];
     const int npix = B * h * w;
     for (int p = 0; p < 2; ++p) {
@@ -864,10 +900,15 @@ int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
             x = o; xcs = 128;
             o = (o == a) ? b : a;
         }
+        char nm7[64];
         snprintf(nm, sizeof nm, "PoseNet2D/conv%d_6", p + 6);
-        CHK(run_conv(ctx, CL(ctx, nm), x, 128, B, h, w, o, 128, 0, nullptr, nullptr, f16));
-        snprintf(nm, sizeof nm, "PoseNet2D/conv%d_7", p + 6);
-        CHK(run_conv(ctx, CL(ctx, nm), o, 128, B, h, w, ctx->d_sm[p + 1], 32, 0, nullptr, nullptr, f16, 1));
+        snprintf(nm7, sizeof nm7, "PoseNet2D/conv%d_7", p + 6);
+        const int fused = f16 ? 0 : run_pw2(ctx, CL(ctx, nm), CL(ctx, nm7), x, 128, B, h, w, ctx->d_sm[p + 1], 32);
+        if (fused < 0) return fused;
+        if (!fused) {
+            CHK(run_conv(ctx, CL(ctx, nm), x, 128, B, h, w, o, 128, 0, nullptr, nullptr, f16));
+            CHK(run_conv(ctx, CL(ctx, nm7), o, 128, B, h, w, ctx->d_sm[p + 1], 32, 0, nullptr, nullptr, f16, 1));
+        }
     }
     return 0;
 }
@@ -1191,7 +1232,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1569,6 +1610,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
         return 0;
     }
+    if (k == "pw2" && (v == "0" || v == "1" || v == "force")) { ctx->use_pw2 = v == "0" ? 0 : v == "1" ? 1 : 2; return 0; }
     if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
@@ -2292,6 +2334,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }
+    if (k == "conv_pw2_launches") { *value = ctx->conv_pw2_launches + (ctx->kid ? ctx->kid->conv_pw2_launches : 0); return 0; }
     if (k == "conv_wino7_launches") { *value = ctx->conv_wino7_launches + (ctx->kid ? ctx->kid->conv_wino7_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }

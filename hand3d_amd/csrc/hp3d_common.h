@@ -321,6 +321,16 @@ size_t wino7_packed_floats(int cin_pad, int cout_pad);
 void wino7_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items);
 int conv_wino7_launch(const ConvParams& p, hipStream_t s);
+// conv_pw2.hip: two 1x1 convolutions as one launch (the head pairs of both trunks): out = act2((act1(x W1 + b1)) W2 + b2); x [npix, >= 128 ch],
+// W1 / W2 in conv_mfma.hip's packed order (pack_conv, k = 1), hidden width H a multiple of 128, 32 padded output channels
+struct Pw2Params {
+    const float* in; int in_cs; long npix;
+    const float* w1; const float* b1; int H; int act1;
+    const float* w2; const float* b2; int act2;
+    float* out; int out_cs; int cout_store;
+};
+int conv_pw2_eligible(int cin_pad, int hidden_pad, int cout2_pad, long npix, int in_cs, int out_cs);
+int conv_pw2_launch(const Pw2Params& p, hipStream_t s);
 // > 0: conv_wino4_launch would share the last round of this layer out as tail pieces (given the scratch); channel steps per workgroup
 int conv_wino4_tail_plan(int Cin, int Cout, int Ho, int Wo, int B, int* tail_items);
 int conv_wino_launch(const ConvParams& p, int pool, hipStream_t s);

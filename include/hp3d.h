@@ -103,6 +103,10 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            split) when the launch fills the chip (>= 160 work items: B >= 20 on the 32 x 32 score maps) | never (the
  *                            nine-3x3-block form on conv_wino4.hip / conv_wino2.hip) | whenever the shape allows (tests).  Float32 throughout,
  *                            the same rounding error as the nine-block form (profiles/r05_wino7_numerics.md);
+ *          "pw2"          = "1" (default) | "0" | "force": the 1x1 head pairs of both trunks (conv6_1 + conv6_2; conv5_1 + conv5_2, conv6_6 + conv6_7,
+ *                            conv7_6 + conv7_7: ColorHandPose3DNetwork.py:160-161,202-203,213-214) as ONE launch each with the wide intermediate in
+ *                            LDS (conv_pw2.hip, round 5) when the launch has a workgroup of 64 pixels per CU | two launches of the general kernel |
+ *                            whenever the shapes allow (tests).  Float32 mode only;
  *          "wino4_tail"   = "1" (default) | "0": conv_wino4.hip deals its work items round-robin to one workgroup per CU; when the last
  *                            round is at most half full (HandSegNet's 40x40 layers at B = 32: 800 items on 256 CUs = 3.125 rounds) its
  *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
@@ -267,7 +271,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
  * layers that ran on conv_h16.hip (option "f16_impl"); "conv_wino2_launches" = float32 layers that ran on conv_wino2.hip (option
  * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4"),
  * "conv_wino4_tail_launches" = those of them whose last round ran as channel slices (option "wino4_tail");
- * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7");
+ * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7"); "conv_pw2_launches" = 1x1 layer pairs that ran as one launch (option "pw2");
  * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);

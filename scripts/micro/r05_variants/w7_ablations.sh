@@ -8,7 +8,7 @@ T=/tmp/w7var; mkdir -p $T
 variant() {   # name, sed program
   sed -E "$2" $C/conv_wino7.hip > $T/conv_wino7_$1.hip
   ( /opt/rocm/bin/hipcc $F -c $T/conv_wino7_$1.hip -o $T/conv_wino7_$1.o &&
-    OBJS=""; for f in conv_mfma conv_wino conv_wino2 conv_wino4 conv_first conv_h16 glue lift_fused engine; do OBJS="$OBJS $C/$f.o"; done;
+    OBJS=""; for f in conv_mfma conv_wino conv_wino2 conv_wino4 conv_pw2 conv_first conv_h16 glue lift_fused engine; do OBJS="$OBJS $C/$f.o"; done;
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o hand3d_amd/libhp3d_w7_$1.so $OBJS $T/conv_wino7_$1.o && echo built $1 ) &
 }
 variant base   's/^XXXX//'

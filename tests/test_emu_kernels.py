@@ -125,6 +125,19 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
         emu_engine.set_option('wino7', 'auto')
     for a, b in zip(sms_7, ref):
         assert np.abs(a - b).max() < 3e-5
+    # ... and the 1x1 head pairs (conv6_1 + conv6_2 of HandSegNet; conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7 of PoseNet2D) as one launch
+    # each on conv_pw2.hip: a partial 64-pixel tile, the 160-channel concat buffer as input, hidden widths 512 and 128, 2 / 21 real couts
+    emu_engine.set_option('pw2', 'force')
+    try:
+        n0 = emu_engine.counter('conv_pw2_launches')
+        _, small_p = emu_engine.handsegnet(img, want_small=True)
+        sms_p = net.inference_pose2d(crop)
+        assert emu_engine.counter('conv_pw2_launches') == n0 + 4
+    finally:
+        emu_engine.set_option('pw2', '1')
+    assert np.abs(small_p - rs).max() < 1e-5
+    for a, b in zip(sms_p, ref):
+        assert np.abs(a - b).max() < 1e-5
     rng = np.random.default_rng(5)
     sm32 = (rng.standard_normal((2, 32, 32, 21)) * 0.3).astype(np.float32)
     hs = synth.hand_sides(2)

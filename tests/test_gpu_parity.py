@@ -625,8 +625,9 @@ def test_full_pipeline_batch32_winograd_active(net, synth_weights):
     from hand3d_amd.utils.general import EvalUtil
     img = synth.make_batch(3000, 32, 320, 320)
     hs = synth.hand_sides(32)
-    c0, c7 = net.engine.counter('conv_wino4_launches'), net.engine.counter('conv_wino7_launches')
+    c0, c7, cp = net.engine.counter('conv_wino4_launches'), net.engine.counter('conv_wino7_launches'), net.engine.counter('conv_pw2_launches')
     o = net.engine.infer_full(img, hs, want_mask=True)
+    assert net.engine.counter('conv_pw2_launches') - cp == 4, "the 1x1 head pairs did not run as one launch each (conv_pw2.hip)"
     assert net.engine.counter('conv_wino4_launches') - c0 >= 26, "the F(4x4,3x3) kernel did not take the 3x3 trunk layers"
     assert net.engine.counter('conv_wino7_launches') - c7 == 10, "the F(4x4,4x4) kernel did not take the ten 7x7 layers"
     net.engine.set_profiling(1)
@@ -1111,6 +1112,37 @@ def test_conv7x7_as_four_4x4_blocks_f4x4_vs_oracle(gpu_engine, case):
     e7, e9 = float(np.abs(y - r).max()), float(np.abs(y9 - r).max())
     print("7x7 as four 4x4 blocks %s: F(4x4,4x4) %.2e from the float64 oracle, the nine-block F(4x4,3x3) form %.2e" % (case, e7, e9))
     assert y.shape == r.shape and e7 < 1e-4 and e7 < 3 * e9 + 2e-5
+
+
+def test_1x1_head_pairs_as_one_launch_vs_two(gpu_engine, synth_weights):
+    """conv_pw2.hip (round 5): conv6_1 + conv6_2 of HandSegNet and conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7 of PoseNet2D
+    (nets/ColorHandPose3DNetwork.py:160-161,202-203,213-214) as ONE launch each, the 512- / 128-channel intermediate in LDS.  B = 24 at
+    200 x 264 (25 x 33 maps: a ragged last tile of 64 pixels) and a 256 x 256 crop batch: against the two-launch form of the same engine
+    (float32 accumulation in another blocking: 1e-5) and against the float64 oracle on one image; the counter proves which path ran."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=gpu_engine)
+    net.init_from_dict(synth_weights)
+    img = synth.make_batch(4100, 24, 200, 264)
+    crop = synth.make_batch(4200, 24, 256, 256)
+    outs = {}
+    try:
+        for mode in ('0', '1'):
+            gpu_engine.set_option('pw2', mode)
+            n0 = gpu_engine.counter('conv_pw2_launches')
+            _, small = gpu_engine.handsegnet(img, want_small=True)
+            sms = net.inference_pose2d(crop)
+            outs[mode] = (small, sms, gpu_engine.counter('conv_pw2_launches') - n0)
+    finally:
+        gpu_engine.set_option('pw2', '1')
+    assert outs['0'][2] == 0 and outs['1'][2] == 4, (outs['0'][2], outs['1'][2])
+    d_seg = float(np.abs(outs['1'][0] - outs['0'][0]).max())
+    d_sm = max(float(np.abs(a - b).max()) for a, b in zip(outs['1'][1], outs['0'][1]))
+    rs, _ = N.handsegnet(synth_weights, img[:1], acc=np.float64)
+    ref = N.posenet2d(synth_weights, crop[:1], acc=np.float64)
+    e_seg = float(np.abs(outs['1'][0][:1] - rs).max())
+    e_sm = max(float(np.abs(a[:1] - b).max()) for a, b in zip(outs['1'][1], ref))
+    print("1x1 head pairs, one launch vs two: logits %.2e, score maps %.2e; vs the float64 oracle: %.2e, %.2e" % (d_seg, d_sm, e_seg, e_sm))
+    assert d_seg < 1e-5 and d_sm < 1e-5 and e_seg < 1e-4 and e_sm < 1e-4
 
 
 def test_device_keypoints_equal_reference_host_functions(net, synth_weights):

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhp3d.so')
 SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
-HEADERS = ['hp3d_common.h', 'lift_fused.h', 'wino4_shared.h', os.path.join('..', '..', 'include', 'hp3d.h')]
+HEADERS = ['hp3d_common.h', 'lift_fused.h', 'wino4_shared.h', 'wino4_diag.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
 # per-file additions.  conv_wino4.hip: its F(4x4,3x3) transforms are multiply-adds by 2, 4, 5, 8 -- contracted to (packed) FMAs they are

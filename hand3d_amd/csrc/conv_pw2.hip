@@ -31,6 +31,7 @@ constexpr int PW_PX = 64;                  // pixels per workgroup
 constexpr int PW_C = 128;                  // input channels (all four call sites) = channels per hidden slab
 constexpr int PW_PITCH = PW_C + 4;         // LDS row pitch in floats
 constexpr int PW_SMEM_BYTES = 2 * PW_PX * PW_PITCH * 4;       // x tile + hidden slab: 67584 B
+constexpr int PW_RING = 4;                 // stage-1 weight fragments in flight (8-channel steps)
 
 HP3D_KERNEL2(256, 2)
 void conv_pw2_kernel(const Pw2Params p) {
@@ -68,16 +69,28 @@ void conv_pw2_kernel(const Pw2Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
         const int co32 = slab * 4 + wave;
+        // weight fragments through a ring of PW_RING 8-channel steps (left to itself the compiler keeps ONE step in flight: an L2 round trip
+        // per 512 matrix-core cycles), A fragments one step ahead; the scheduling barriers pin that order
+        f32x4 bw[PW_RING], a0[2], a1[2];
+#pragma unroll
+        for (int t = 0; t < PW_RING; ++t) bw[t] = HP3D_BUFFER_LOAD16(w1rsrc, bl, (t * CO32 + co32) * 1024);
+        a0[0] = *(const f32x4*)((const char*)Xs + arow);
+        a1[0] = *(const f32x4*)((const char*)Xs + arow + 32 * PW_PITCH * 4);
 #pragma unroll
         for (int c8 = 0; c8 < PW_C / 8; ++c8) {
-            const f32x4 b = HP3D_BUFFER_LOAD16(w1rsrc, bl, (c8 * CO32 + co32) * 1024);
-            const f32x4 a0 = *(const f32x4*)((const char*)Xs + arow + c8 * 32);
-            const f32x4 a1 = *(const f32x4*)((const char*)Xs + arow + 32 * PW_PITCH * 4 + c8 * 32);
+            HP3D_SCHED_BARRIER();
+            if (c8 + 1 < PW_C / 8) {
+                a0[(c8 + 1) & 1] = *(const f32x4*)((const char*)Xs + arow + (c8 + 1) * 32);
+                a1[(c8 + 1) & 1] = *(const f32x4*)((const char*)Xs + arow + 32 * PW_PITCH * 4 + (c8 + 1) * 32);
+            }
+            const f32x4 b = bw[c8 % PW_RING];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                acc[0] = HP3D_MFMA_32x32x2(a0[j], b[j], acc[0]);
-                acc[1] = HP3D_MFMA_32x32x2(a1[j], b[j], acc[1]);
+                acc[0] = HP3D_MFMA_32x32x2(a0[c8 & 1][j], b[j], acc[0]);
+                acc[1] = HP3D_MFMA_32x32x2(a1[c8 & 1][j], b[j], acc[1]);
             }
+            HP3D_SCHED_BARRIER();
+            if (c8 + PW_RING < PW_C / 8) bw[c8 % PW_RING] = HP3D_BUFFER_LOAD16(w1rsrc, bl, ((c8 + PW_RING) * CO32 + co32) * 1024);
         }
         // bias + leaky-ReLU, slab -> LDS: accumulator r of lane l is pixel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the half, hidden channel 32 wave + (l & 31)
         const float b1 = p.b1[co32 * 32 + n];
@@ -93,13 +106,15 @@ void conv_pw2_kernel(const Pw2Params p) {
         __syncthreads();
         // ---- stage 2: Y[32 px of half w & 1][32] += S[:, 64 channels of half w >> 1] W2 ------------------------------------------------------
         const int ph = wave & 1, ch = wave >> 1;
+        f32x4 b2w[8];          // (the slab's eight W2 fragments of this wave: all requested up front, they do not depend on the slab in LDS)
+#pragma unroll
+        for (int c8l = 0; c8l < 8; ++c8l) b2w[c8l] = HP3D_BUFFER_LOAD16(w2rsrc, bl, (slab * 16 + ch * 8 + c8l) * 1024);
 #pragma unroll
         for (int c8l = 0; c8l < 8; ++c8l) {
             const int c8 = ch * 8 + c8l;
-            const f32x4 b = HP3D_BUFFER_LOAD16(w2rsrc, bl, (slab * 16 + c8) * 1024);
             const f32x4 a = *(const f32x4*)((const char*)Hs + arow + ph * 32 * PW_PITCH * 4 + c8 * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc2 = HP3D_MFMA_32x32x2(a[j], b[j], acc2);
+            for (int j = 0; j < 4; ++j) acc2 = HP3D_MFMA_32x32x2(a[j], b2w[c8l][j], acc2);
         }
     }
     // ---- the two channel halves meet: waves 2, 3 hand their sums to waves 0, 1 through LDS (Xs is free), then bias + activation + store ------

@@ -36,19 +36,11 @@
 #include <cstring>
 #include <type_traits>
 
-#ifndef HP3D_W4_ABL
-#define HP3D_W4_ABL 0            // timing ablations (scripts/gpu_ab.sh with build_variant.sh -DHP3D_W4_ABL=n); any non-zero value computes wrong results
-#endif
-
-#ifndef HP3D_W4_TIMING
-#define HP3D_W4_TIMING 0         // 1: diagnostic build -- every wave sums shader-clock intervals of its steps (planes 0..28 | window wait +
-#endif                           // transform | planes 30..35 | barrier | epilogue) into w4_timing[]; conv_wino4_launch prints them (profiles/r04_tuning_notes.md)
 #define W4_WLOAD HP3D_BUFFER_LOAD8
-
-#if HP3D_W4_TIMING
-__device__ unsigned long long w4_timing[8];
-#define W4_CLOCK() __builtin_readcyclecounter()
-#endif
+// -DHP3D_W4_TIMING=1: diagnostic build -- every wave sums shader-clock intervals of its steps into w4_timing[] and conv_wino4_launch prints
+// them (wino4_diag.h; profiles/r04_tuning_notes.md section 4).  The shipped build sees empty macros.  (Round 4's timing ABLATIONS -- builds
+// that compute wrong results on purpose, HP3D_W4_ABL -- were removed from this file in round 5: all settled, recorded in r03 / r04_tuning_notes.md.)
+#include "wino4_diag.h"
 
 namespace {
 
@@ -142,23 +134,12 @@ void conv_wino4_kernel(const ConvParams p) {
     auto window_offsets = [&](bool valid, int lb, int lty, int ltx, int sub) {
         const int dy = NSUB == 1 ? 0 : 3 * (sub / 3) - 2, dx = NSUB == 1 ? 0 : 3 * (sub % 3) - 2;
         const int wy0 = 4 * lty - 1 + dy, wx0 = 4 * ltx - 1 + dx;
-#if HP3D_W4_ABL & 1024       // timing ablation: the ADDRESS pattern of a channel-blocked tensor [B][H][C/16][W][16] (same bytes, permuted)
-        const int rowb = (p.in_cs / 16) * p.W * 64;
-        const int wbase = (lb * p.H + wy0) * rowb + wx0 * 64 + lp * 8;
-#else
         const int wbase = ((lb * p.H + wy0) * p.W + wx0) * cs4 + lp * 8;
-#endif
         const bool tv = valid && lb < p.B;
 #pragma unroll
-        for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * ((HP3D_W4_ABL & 1024) ? (p.in_cs / 16) * p.W * 64 : p.W * cs4) : OOR;
+        for (int r = 0; r < 6; ++r) ro[r] = (tv && (unsigned)(wy0 + r) < (unsigned)p.H) ? wbase + r * (p.W * cs4) : OOR;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * ((HP3D_W4_ABL & 1024) ? 64 : cs4) : COL_OOR;
-#if HP3D_W4_ABL & 128        // hot windows: every load of the launch comes from one 18 KB region
-#pragma unroll
-        for (int r = 0; r < 6; ++r) ro[r] = r * 3072 + lp * 8 + (lt & 7) * 64;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) co[c] = c * 512;
-#endif
+        for (int c = 0; c < 6; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * cs4 : COL_OOR;
     };
     auto loader_setup = [&](int tblock, bool valid, int sub) {
         int lb, lty, ltx;
@@ -181,19 +162,15 @@ void conv_wino4_kernel(const ConvParams p) {
     auto transform_arith = [&]() {
 #pragma unroll
         for (int c = 0; c < 6; ++c)
-            if (!(HP3D_W4_ABL & 32)) w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
+            w4_bt(d[0 * 6 + c], d[1 * 6 + c], d[2 * 6 + c], d[3 * 6 + c], d[4 * 6 + c], d[5 * 6 + c]);
 #pragma unroll
         for (int a = 0; a < 6; ++a)
-            if (!(HP3D_W4_ABL & 32)) w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
+            w4_bt(d[a * 6 + 0], d[a * 6 + 1], d[a * 6 + 2], d[a * 6 + 3], d[a * 6 + 4], d[a * 6 + 5]);
     };
     auto v_write = [&](int buf, int pl) {
         float* Vq0 = Vw + buf * W4_VBUF_FLOATS;
         float* dst = pl < W4_HALF ? Vq0 + pl * W4_PLANE_FLOATS : Vq0 + W4_HALF * W4_PLANE_FLOATS + (pl - W4_HALF) * W4_PLANE_FLOATS;
-#if HP3D_W4_ABL & 64
-        asm volatile("" :: "v"(d[pl]));
-#else
         *(f32x2*)dst = d[pl];
-#endif
     };
     auto transform_commit = [&](int buf) {
         transform_arith();
@@ -269,16 +246,14 @@ void conv_wino4_kernel(const ConvParams p) {
     loader_setup(tblock, true, sub0);
     table_write(tblock, 0, kz, piece);
     int wvoff = (cy * (W4_COUTS / 16) + wave) * 1024 + lane * 16;
-    window_fetch((s0 - sub0 * csteps) * ((HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4));
+    window_fetch((s0 - sub0 * csteps) * (W4_CK * 4));
 #pragma unroll
     for (int t = 0; t < W4_RING; ++t) b_fetch(t, wvoff, soff_of(t, s0));
     transform_commit(0);
     __syncthreads();
     int cur = 0;
 
-#if HP3D_W4_TIMING
-    unsigned long long tsum[6] = {0, 0, 0, 0, 0, 0}, t_mark = W4_CLOCK();
-#endif
+    W4_T_DECL();
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_wvoff = wvoff, n_kz = kz, n_s0 = s0, n_s1 = s1, n_piece = -1;
         const int n_item = next_of(item);
@@ -295,9 +270,7 @@ void conv_wino4_kernel(const ConvParams p) {
             const int skip_ab = (NSUB == 9 && !FIRST) ? HP3D_OPAQUE_SGPR((za || zb) ? 1 : 0) : 0;
             const int nvoff = lasts ? n_wvoff : wvoff;
             const int nstep = lasts ? (VARSTEPS ? n_s0 : 0) : step + 1;
-#if HP3D_W4_TIMING
-            { const unsigned long long t = W4_CLOCK(); tsum[4] += t - t_mark; t_mark = t; }      // (item switch / epilogue / step prologue)
-#endif
+            W4_T_MARK(4);      // (item switch / epilogue / step prologue)
             ab0 = cur * (W4_VBUF_FLOATS * 4) + va_lane;
             ab1 = ab0 + W4_HALF * W4_PLANE_FLOATS * 4;
             HP3D_OPAQUE_V(ab0);
@@ -308,7 +281,7 @@ void conv_wino4_kernel(const ConvParams p) {
             const int ncs = NSUB == 1 ? nstep : nstep - nsub_ * csteps;
             if (lasts) loader_setup(n_tblock, n_item >= 0, nsub_);
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
-            const int wstep_b = (HP3D_W4_ABL & 1024) ? p.W * 64 : W4_CK * 4;
+            const int wstep_b = W4_CK * 4;
             const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * wstep_b) : ncs * wstep_b;
             // The plane as four PAIRS of MFMAs (one k quad, both tile halves) with ONE of the plane's other instructions after each: the next
             // plane's A fragments | window load | window load | the weight fragment for the slot this plane releases.  Each issues under the
@@ -335,24 +308,21 @@ void conv_wino4_kernel(const ConvParams p) {
                         }
                         HP3D_SCHED_BARRIER();
                         if (e == 0) {
-                            if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
+                            if (pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
                         } else if (e == 3) {
                             // weight prefetch W4_RING planes ahead into the slot this plane just released
                             const int t = pl + W4_RING;
-                            if (HP3D_W4_ABL & 8) {}
-                            else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                            if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
                             else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
                         } else if (pl > W4_TRANSFORM_AT) {
                             // V of the next step: the 36 values this thread transformed under plane 29 go to LDS three behind each of the two
                             // middle pairs of planes 30..35 (as one burst under plane 29 the four waves queued 74 KB on the LDS port at once and
                             // each sat ~900 cycles in front of its next MFMA: timing ablations, round-4 log section 5)
-                            if (!(HP3D_W4_ABL & 1)) {
-                                constexpr int PER = 36 / (2 * (W4_NP - 1 - W4_TRANSFORM_AT));
-                                static_assert(PER * 2 * (W4_NP - 1 - W4_TRANSFORM_AT) == 36, "");
+                            constexpr int PER = 36 / (2 * (W4_NP - 1 - W4_TRANSFORM_AT));
+                            static_assert(PER * 2 * (W4_NP - 1 - W4_TRANSFORM_AT) == 36, "");
 #pragma unroll
-                                for (int j = 0; j < PER; ++j) v_write(cur ^ 1, ((pl - W4_TRANSFORM_AT - 1) * 2 + (e - 1)) * PER + j);
-                            }
-                        } else if (!(HP3D_W4_ABL & 2)) {
+                            for (int j = 0; j < PER; ++j) v_write(cur ^ 1, ((pl - W4_TRANSFORM_AT - 1) * 2 + (e - 1)) * PER + j);
+                        } else {
                             static_assert(W4_WPP % 2 == 0, "the plane's window loads go behind its two middle pairs, half each");
 #pragma unroll
                             for (int j = 0; j < W4_WPP / 2; ++j) {
@@ -366,7 +336,7 @@ void conv_wino4_kernel(const ConvParams p) {
                     }
                 } else {
                     HP3D_SCHED_BARRIER();
-                    if (!(HP3D_W4_ABL & 16) && pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
+                    if (pl + W4_ADEPTH - 1 < W4_NP) a_fetch((pl + W4_ADEPTH - 1) % W4_ADEPTH, pl + W4_ADEPTH - 1);
                     // the eight MFMAs of the plane (two tile halves alternating: 40-cycle dependent latency vs 32-cycle issue) as ONE
                     // statement that pins the accumulators' register file: planes 0..31 in the 256 AGPRs, planes 32..35 in arch VGPRs.
                     // 7x7 filters: in the edge blocks of the zero-extended 9x9 filter (i = 2 / j = 2: one filter row / column of three)
@@ -381,42 +351,30 @@ void conv_wino4_kernel(const ConvParams p) {
                     }
                     // weight prefetch W4_RING planes ahead into the slot this plane just released
                     const int t = pl + W4_RING;
-                    if (HP3D_W4_ABL & 8) {}
-                    else if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
+                    if (t < W4_NP) b_fetch(t % W4_RING, wvoff, soff_of(t, step));
                     else b_fetch(t % W4_RING, nvoff, soff_of(t - W4_NP, nstep));
-                    if (!(HP3D_W4_ABL & 2) && pl * W4_WPP < 36) {
+                    if (pl * W4_WPP < 36) {
     #pragma unroll
                         for (int j = 0; j < W4_WPP; ++j) {        // (indices are constants once the plane loop is unrolled)
                             const int e = W4_ISSUE_ELEM(pl * W4_WPP + j);
                             d[e] = W4_WLOAD(irsrc, (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]), wsoff);
                         }
                     }
-                    if (!(HP3D_W4_ABL & 1) && pl > W4_TRANSFORM_AT) {          // V of the next step, six values per plane (see the pair form)
+                    if (pl > W4_TRANSFORM_AT) {          // V of the next step, six values per plane (see the pair form)
     #pragma unroll
                         for (int j = 0; j < 36 / (W4_NP - 1 - W4_TRANSFORM_AT); ++j) v_write(cur ^ 1, (pl - W4_TRANSFORM_AT - 1) * (36 / (W4_NP - 1 - W4_TRANSFORM_AT)) + j);
                     }
                 }
-                if (!(HP3D_W4_ABL & 1) && pl == W4_TRANSFORM_AT) {
-#if HP3D_W4_TIMING
-                    { const unsigned long long t = W4_CLOCK(); tsum[0] += t - t_mark; t_mark = t; }
-                    // the windows are in once at most the weight fragments issued behind the last window load (planes 36 / WPP .. TRANSFORM_AT) are out
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W4_TRANSFORM_AT + 1 - 36 / W4_WPP) : "memory");
-                    { const unsigned long long t = W4_CLOCK(); tsum[5] += t - t_mark; t_mark = t; }
-#endif
+                if (pl == W4_TRANSFORM_AT) {
+                    W4_T_WINDOW_WAIT(W4_TRANSFORM_AT + 1 - 36 / W4_WPP);      // (timing build: marks 0 and 5 around the wait for the window data)
                     transform_arith();
-#if HP3D_W4_TIMING
-                    { const unsigned long long t = W4_CLOCK(); tsum[1] += t - t_mark; t_mark = t; }
-#endif
+                    W4_T_MARK(1);
                 }
             }
             HP3D_SCHED_BARRIER();
-#if HP3D_W4_TIMING
-            { const unsigned long long t = W4_CLOCK(); tsum[2] += t - t_mark; t_mark = t; }
-#endif
-            if (!(HP3D_W4_ABL & 4)) __syncthreads();             // V[cur^1] complete, V[cur] free
-#if HP3D_W4_TIMING
-            { const unsigned long long t = W4_CLOCK(); tsum[3] += t - t_mark; t_mark = t; }
-#endif
+            W4_T_MARK(2);
+            __syncthreads();             // V[cur^1] complete, V[cur] free
+            W4_T_MARK(3);
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };
@@ -461,14 +419,12 @@ void conv_wino4_kernel(const ConvParams p) {
                 float z[6][4];                               // A^T M: along the plane rows a
 #pragma unroll
                 for (int b = 0; b < 6; ++b)
-                    if (HP3D_W4_ABL & 512) { z[b][0] = M[b][m][r]; z[b][1] = M[6 + b][m][r]; z[b][2] = M[12 + b][m][r]; z[b][3] = M[18 + b][m][r] + M[24 + b][m][r] + M[30 + b][m][r]; }
-                    else w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
+                    w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
                           z[b][0], z[b][1], z[b][2], z[b][3]);
                 float y[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (HP3D_W4_ABL & 512) { y[i][0] = z[0][i]; y[i][1] = z[1][i]; y[i][2] = z[2][i]; y[i][3] = z[3][i] + z[4][i] + z[5][i]; }
-                    else w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
+                    w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
                     if (!POOL && !raw) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
@@ -490,8 +446,7 @@ void conv_wino4_kernel(const ConvParams p) {
                                 float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
                                 v = fmaxf(v, slope * v);
                                 const bool ok = FULL || ((pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2)));
-                                if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(v), "v"(ok ? vo : OOR));
-                                else HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
+                                HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
                             }
                     } else {
                         const int vr = fl & 15, vc = fl >> 4;
@@ -499,10 +454,7 @@ void conv_wino4_kernel(const ConvParams p) {
                         for (int i = 0; i < 4; ++i) {
                             const int vrow = (FULL || i < vr) ? vo : OOR;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                if (HP3D_W4_ABL & 256) asm volatile("" :: "v"(y[i][j]), "v"((FULL || j < vc) ? vrow : OOR));
-                                else HP3D_BUFFER_STORE4(orsrc, y[i][j], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
-                            }
+                            for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, y[i][j], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
                         }
                     }
                 };
@@ -510,16 +462,7 @@ void conv_wino4_kernel(const ConvParams p) {
                 else store_tile(std::false_type{});
             }
         }
-#if HP3D_W4_TIMING
-        if (n_item < 0) {
-            const unsigned long long t = W4_CLOCK();
-            tsum[4] += t - t_mark;
-            if (lane == 0) {
-                for (int i = 0; i < 6; ++i) atomicAdd(&w4_timing[i], tsum[i]);
-                atomicAdd(&w4_timing[6], 1ull);
-            }
-        }
-#endif
+        if (n_item < 0) W4_T_FLUSH(lane);
         if (n_item < 0) break;
         item = n_item; cy = n_cy; tblock = n_tblock; wvoff = n_wvoff;
         if (VARSTEPS) { kz = n_kz; piece = n_piece; s0 = n_s0; s1 = n_s1; }
@@ -638,20 +581,6 @@ static void wino4_launch_t(const ConvParams& p, long tiles, hipStream_t s) {
 // conv_splitk_reduce afterwards (bias + activation happen there).
 // Returns < 0: refused; 0: launched; 1: launched AND the last round ran as tail pieces (the scratch alone does not say so: an unaligned
 // output or a pooled layer with cout_store % 4 != 0 drops the tail here).
-#if HP3D_W4_TIMING
-static void w4_timing_report(const ConvParams& p, hipStream_t s, const char* what) {
-    unsigned long long h[8] = {};
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(w4_timing), sizeof(h));
-    if (h[6]) {
-        const double w = (double)h[6];
-        fprintf(stderr, "w4_timing %s Cin %d Cout %d %dx%d B %d: per wave (cycles) planes 0..28 %.0f | window wait %.0f | transform %.0f | planes 30..35 %.0f | barrier %.0f | "
-                        "between steps / epilogue %.0f | waves %.0f\n", what, p.Cin, p.Cout, p.Ho, p.Wo, p.B, h[0] / w, h[5] / w, h[1] / w, h[2] / w, h[3] / w, h[4] / w, w);
-    }
-    unsigned long long z[8] = {};
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(w4_timing), z, sizeof(z));
-}
-#endif
 int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
     const long kso = pin.ksplit > 1 ? pin.ksplit : 1;
     if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || kso * pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
@@ -666,18 +595,14 @@ int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
         const int nsteps = p.nsub * p.Cin / W4_CK;
         if (pool || p.ksplit * 2 > nsteps || p.out_cs != p.Cout) return -1;
         if (p.nsub == 9) wino4_launch_t<false, 9, true, false>(p, tiles, s); else wino4_launch_t<false, 1, true, false>(p, tiles, s);
-#if HP3D_W4_TIMING
-        w4_timing_report(p, s, p.nsub == 9 ? "7x7 split" : "3x3 split");
-#endif
+        W4_T_REPORT(p, s, p.nsub == 9 ? "7x7 split" : "3x3 split");
         return 0;
     }
     p.ksplit = 1;
     p.tail_items = p.tail_q = 0;
     if (p.nsub == 9) {
         wino4_launch_t<false, 9, false, false>(p, tiles, s);
-#if HP3D_W4_TIMING
-        w4_timing_report(p, s, "7x7");
-#endif
+        W4_T_REPORT(p, s, "7x7");
         return 0;
     }
     // 3x3: the same instantiation serves launches with and without tail pieces (tail_items = 0: every item is a whole item)
@@ -685,9 +610,7 @@ int conv_wino4_launch(const ConvParams& pin, int pool, hipStream_t s) {
         p.tail_q = conv_wino4_tail_plan(p.Cin, p.Cout, p.Ho, p.Wo, p.B, &p.tail_items);
     if (pool) wino4_launch_t<true, 1, false, true>(p, tiles, s);
     else wino4_launch_t<false, 1, false, true>(p, tiles, s);
-#if HP3D_W4_TIMING
-    w4_timing_report(p, s, pool ? "3x3 pool" : "3x3");
-#endif
+    W4_T_REPORT(p, s, pool ? "3x3 pool" : "3x3");
     if (p.tail_items > 0) {
         const long total = (long)p.tail_items * W4_TILES * (pool ? 4 : 16) * (W4_COUTS / 4);
         const unsigned blocks = (unsigned)((total + 255) / 256);

@@ -30,8 +30,10 @@ def family(name):
         return 'conv_wino'
     if 'conv_wino2_kernel' in name:
         return 'conv_wino2'
-    if 'conv_wino4_kernel' in name:
+    if 'conv_wino4_kernel' in name or 'conv_wino7_kernel' in name:      # (bench.py's family: Winograd with 4x4 output tiles, F(4x4,3x3) and the 7x7 layers' F(4x4,4x4))
         return 'conv_wino4'
+    if 'conv_pw2_kernel' in name:
+        return 'conv_pw2'
     if 'lift_fused_kernel' in name:
         return 'lift_fused'
     if 'conv_mfma_kernel' in name:

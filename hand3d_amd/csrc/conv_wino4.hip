@@ -408,32 +408,39 @@ void conv_wino4_kernel(const ConvParams p) {
         const int cout_off = raw ? wave * 16 + ln : cout;                // a piece holds the item's 64 couts only
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(raw ? (float*)p.partial : p.out, raw ? 2u * gridDim.x * (unsigned)(W4_PIECE_FLOATS * 4) : out_bytes);
         const int srow = raw ? 4 * W4_COUTS * 4 : Ws * p.out_cs * 4, scol = raw ? W4_COUTS * 4 : p.out_cs * 4;      // byte strides of the 4x4 block
+        // The two tile halves m = 0, 1 of an accumulator pair (same register index r, same cout) go through A^T . A as ONE packed value: the
+        // output transform is 100 additions / multiply-adds per (tile, cout), and an instruction costs the f32 matrix pipe the same 4-5 cycles
+        // whether it carries one float or two (round 5: the pooled epilogue was all scalar -- 832 transform instructions per item and wave)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int r = 0; r < 4; ++r) {
+            f32x2 z[6][4];                               // A^T M: along the plane rows a
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int b = 0; b < 6; ++b)
+                w4_at_t<f32x2>(f32x2{M[0 * 6 + b][0][r], M[0 * 6 + b][1][r]}, f32x2{M[1 * 6 + b][0][r], M[1 * 6 + b][1][r]}, f32x2{M[2 * 6 + b][0][r], M[2 * 6 + b][1][r]},
+                               f32x2{M[3 * 6 + b][0][r], M[3 * 6 + b][1][r]}, f32x2{M[4 * 6 + b][0][r], M[4 * 6 + b][1][r]}, f32x2{M[5 * 6 + b][0][r], M[5 * 6 + b][1][r]},
+                               z[b][0], z[b][1], z[b][2], z[b][3]);
+            f32x2 yy[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                w4_at_t<f32x2>(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], yy[i][0], yy[i][1], yy[i][2], yy[i][3]);
+                if (!POOL && !raw) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x2 x = yy[i][j] + bias;
+                        if (!SPLITK) {                      // (slope 1 = a linear layer: max(x, x); no per-value select on p.act)
+                            const f32x2 sx = slope * x;
+                            x = f32x2{fmaxf(x[0], sx[0]), fmaxf(x[1], sx[1])};
+                        }
+                        yy[i][j] = x;
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
                 const int t = 16 * m + 4 * lq + r;          // MFMA row = Winograd tile
                 const int off = tab[t];
                 const int fl = tab[W4_TILES + t];
                 const int vo = (cok && off >= 0) ? (off + cout_off) * 4 : OOR;
-                float z[6][4];                               // A^T M: along the plane rows a
-#pragma unroll
-                for (int b = 0; b < 6; ++b)
-                    w4_at(M[0 * 6 + b][m][r], M[1 * 6 + b][m][r], M[2 * 6 + b][m][r], M[3 * 6 + b][m][r], M[4 * 6 + b][m][r], M[5 * 6 + b][m][r],
-                          z[b][0], z[b][1], z[b][2], z[b][3]);
-                float y[4][4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    w4_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], y[i][0], y[i][1], y[i][2], y[i][3]);
-                    if (!POOL && !raw) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float x = y[i][j] + bias;
-                            if (!SPLITK) x = fmaxf(x, slope * x);           // (slope 1 = a linear layer: max(x, x); no per-value select on p.act)
-                            y[i][j] = x;
-                        }
-                    }
-                }
                 auto store_tile = [&](auto full_tag) {
                     constexpr bool FULL = decltype(full_tag)::value;       // no edge selects: every store of the tile goes to `vo`
                     if (POOL && !raw) {
@@ -443,7 +450,7 @@ void conv_wino4_kernel(const ConvParams p) {
                             for (int pj = 0; pj < 2; ++pj) {
                                 // bias + leaky-ReLU AFTER the max: x -> fl(x + bias) and the leaky-ReLU are monotonic, so
                                 // max_i act(fl(y_i + b)) == act(fl(max_i y_i + b)) bit for bit -- 4 instead of 16 per tile and cout
-                                float v = fmaxf(fmaxf(y[2 * pi][2 * pj], y[2 * pi][2 * pj + 1]), fmaxf(y[2 * pi + 1][2 * pj], y[2 * pi + 1][2 * pj + 1])) + bias;
+                                float v = fmaxf(fmaxf(yy[2 * pi][2 * pj][m], yy[2 * pi][2 * pj + 1][m]), fmaxf(yy[2 * pi + 1][2 * pj][m], yy[2 * pi + 1][2 * pj + 1][m])) + bias;
                                 v = fmaxf(v, slope * v);
                                 const bool ok = FULL || ((pj == 0 || (fl & 1)) && (pi == 0 || (fl & 2)));
                                 HP3D_BUFFER_STORE4(orsrc, v, ok ? vo : OOR, (pi * Ws + pj) * p.out_cs * 4);
@@ -454,7 +461,7 @@ void conv_wino4_kernel(const ConvParams p) {
                         for (int i = 0; i < 4; ++i) {
                             const int vrow = (FULL || i < vr) ? vo : OOR;
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, y[i][j], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
+                            for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, yy[i][j][m], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
                         }
                     }
                 };

@@ -105,8 +105,9 @@ __device__ __forceinline__ void w7_bt(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5, 
     x0 = t0; x1 = t1; x2 = t2; x3 = t3; x4 = t4; x5 = t5; x6 = t6;
 }
 // A^T of F(4,4): [1 1 1 1 1 1 0; 0 1 -1 2 -2 1/2 0; 0 1 1 4 4 1/4 0; 0 1 -1 8 -8 1/8 1]
-__device__ __forceinline__ void w7_at(float m0, float m1, float m2, float m3, float m4, float m5, float m6, float& y0, float& y1, float& y2, float& y3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+template <typename T>
+__device__ __forceinline__ void w7_at(T m0, T m1, T m2, T m3, T m4, T m5, T m6, T& y0, T& y1, T& y2, T& y3) {
+    const T s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
     y0 = ((m0 + s12) + s34) + m5;
     y1 = (d12 + 2.f * d34) + 0.5f * m5;
     y2 = (s12 + 4.f * s34) + 0.25f * m5;
@@ -326,40 +327,47 @@ void conv_wino7_kernel(const ConvParams p) {
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, out_bytes);
         const int srow = p.Wo * p.out_cs * 4, scol = p.out_cs * 4;
         const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0) ? 1 : 0) != 0;
+        // two accumulator registers (tiles 4 lq + 2 rp, + 1 of the same cout) go through A^T . A as ONE packed value: an instruction costs the
+        // f32 matrix pipe the same cycles whether it carries one float or two
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int t = 4 * lq + r;                    // MFMA row = tile of the block
-            const int off = tinfo[t];
-            const int fl = tinfo[W7_TILES + t];
-            const int vo = (cok && off >= 0) ? (off + cout) * 4 : OOR;
-            float z[7][4];                               // A^T M: along the plane rows a
+        for (int rp = 0; rp < 2; ++rp) {
+            f32x2 z[7][4];                               // A^T M: along the plane rows a
 #pragma unroll
             for (int b = 0; b < 7; ++b)
-                w7_at(M[0 * 7 + b][r], M[1 * 7 + b][r], M[2 * 7 + b][r], M[3 * 7 + b][r], M[4 * 7 + b][r], M[5 * 7 + b][r], M[6 * 7 + b][r],
-                      z[b][0], z[b][1], z[b][2], z[b][3]);
-            float y[4][4];
+                w7_at<f32x2>(f32x2{M[0 * 7 + b][2 * rp], M[0 * 7 + b][2 * rp + 1]}, f32x2{M[1 * 7 + b][2 * rp], M[1 * 7 + b][2 * rp + 1]},
+                             f32x2{M[2 * 7 + b][2 * rp], M[2 * 7 + b][2 * rp + 1]}, f32x2{M[3 * 7 + b][2 * rp], M[3 * 7 + b][2 * rp + 1]},
+                             f32x2{M[4 * 7 + b][2 * rp], M[4 * 7 + b][2 * rp + 1]}, f32x2{M[5 * 7 + b][2 * rp], M[5 * 7 + b][2 * rp + 1]},
+                             f32x2{M[6 * 7 + b][2 * rp], M[6 * 7 + b][2 * rp + 1]}, z[b][0], z[b][1], z[b][2], z[b][3]);
+            f32x2 yy[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                w7_at(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], z[6][i], y[i][0], y[i][1], y[i][2], y[i][3]);
+                w7_at<f32x2>(z[0][i], z[1][i], z[2][i], z[3][i], z[4][i], z[5][i], z[6][i], yy[i][0], yy[i][1], yy[i][2], yy[i][3]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float x = y[i][j] + bias;
-                    x = fmaxf(x, slope * x);                // (slope 1 = a linear layer)
-                    y[i][j] = x;
+                    f32x2 x = yy[i][j] + bias;
+                    const f32x2 sx = slope * x;          // (slope 1 = a linear layer)
+                    yy[i][j] = f32x2{fmaxf(x[0], sx[0]), fmaxf(x[1], sx[1])};
                 }
             }
-            auto store_tile = [&](auto full_tag) {
-                constexpr bool FULL = decltype(full_tag)::value;       // no edge selects: every store of the tile goes to `vo`
-                const int vr = fl & 15, vc = fl >> 4;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int vrow = (FULL || i < vr) ? vo : OOR;
+            for (int h = 0; h < 2; ++h) {
+                const int t = 4 * lq + 2 * rp + h;       // MFMA row = tile of the block
+                const int off = tinfo[t];
+                const int fl = tinfo[W7_TILES + t];
+                const int vo = (cok && off >= 0) ? (off + cout) * 4 : OOR;
+                auto store_tile = [&](auto full_tag) {
+                    constexpr bool FULL = decltype(full_tag)::value;       // no edge selects: every store of the tile goes to `vo`
+                    const int vr = fl & 15, vc = fl >> 4;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, y[i][j], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
-                }
-            };
-            if (full) store_tile(std::true_type{});
-            else store_tile(std::false_type{});
+                    for (int i = 0; i < 4; ++i) {
+                        const int vrow = (FULL || i < vr) ? vo : OOR;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) HP3D_BUFFER_STORE4(orsrc, yy[i][j][h], (FULL || j < vc) ? vrow : OOR, i * srow + j * scol);
+                    }
+                };
+                if (full) store_tile(std::true_type{});
+                else store_tile(std::false_type{});
+            }
         }
     }
 }

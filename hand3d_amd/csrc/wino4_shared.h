@@ -36,13 +36,17 @@ __device__ __forceinline__ void w4_bt_t(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5
 __device__ __forceinline__ void w4_bt(f32x2& x0, f32x2& x1, f32x2& x2, f32x2& x3, f32x2& x4, f32x2& x5) {
     w4_bt_t<f32x2>(x0, x1, x2, x3, x4, x5);
 }
-// A^T of F(4x4,3x3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
-    const float s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
+// A^T of F(4x4,3x3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]   (T = float, or f32x2: two accumulators per instruction)
+template <typename T>
+__device__ __forceinline__ void w4_at_t(T m0, T m1, T m2, T m3, T m4, T m5, T& y0, T& y1, T& y2, T& y3) {
+    const T s12 = m1 + m2, d12 = m1 - m2, s34 = m3 + m4, d34 = m3 - m4;
     y0 = (m0 + s12) + s34;
     y1 = d12 + 2.f * d34;
     y2 = s12 + 4.f * s34;
     y3 = (d12 + 8.f * d34) + m5;
+}
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float& y0, float& y1, float& y2, float& y3) {
+    w4_at_t<float>(m0, m1, m2, m3, m4, m5, y0, y1, y2, y3);
 }
 
 // tile / item geometry shared by a convolution kernel and its tail reduction; TILES x COUTS = the item shape

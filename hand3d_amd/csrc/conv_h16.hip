@@ -27,9 +27,6 @@
 // matrix pipe is busy 0.66-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
 #include "hp3d_common.h"
 #include <algorithm>
-#ifndef HP3D_H16_ABL
-#define HP3D_H16_ABL 0          // timing ablations (scripts/build_variant.sh); any non-zero value computes wrong results
-#endif
 
 namespace {
 
@@ -196,7 +193,7 @@ void conv_h16_kernel(const ConvParams p) {
         const int wvoff = (cb * (BN / 32) + wn * NT) * 1024 + lane * 16;
         f32x4 fb[HRING][NT];
         auto b_fetch = [&](int slot, int tap, int kb) {
-            const int soff = (HP3D_H16_ABL & 16) ? 0 : tap * tap_stride_b + kb * (CO32 * 1024);     // ablation 16: always the same 4 KB (L1 hits)
+            const int soff = tap * tap_stride_b + kb * (CO32 * 1024);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) fb[slot][nt] = HP3D_BUFFER_LOAD16(wrsrc, wvoff + nt * 1024, soff);
         };
@@ -296,19 +293,18 @@ void conv_h16_kernel(const ConvParams p) {
                 const int tap = s >> 2, ks = s & 3;
                 HP3D_SCHED_BARRIER();
                 // next chunk's patch, group g: fetched at step g HPSTEP, committed to the other buffer HPSTEP - 1 steps later
-                if (has_next && !(HP3D_H16_ABL & 2)) {
+                if (has_next) {
                     if (s % HPSTEP == 0) patch_fetch(chunk + 1, s / HPSTEP);
                     if (s % HPSTEP == HPSTEP - 1) patch_commit(cur ^ 1, s / HPSTEP);
                 }
                 // prefetch: A fragments of step s+1 (other register set), weight fragments of step s + RING - 1
-                if (s + 1 < NSTEP && !(HP3D_H16_ABL & 8)) {
+                if (s + 1 < NSTEP) {
                     const int t1 = (s + 1) >> 2, r1 = t1 / KS, c1 = t1 - r1 * KS;
                     a_fetch((s + 1) & 1, cur, (r1 * HPW + c1) * HPITCH * 4, (s + 1) & 3);
                 }
                 {
                     const int s2 = s + HRING - 1;
-                    if (HP3D_H16_ABL & 4) { asm volatile("" : "+v"(fb[s2 % HRING][0])); }
-                    else if (s2 < NSTEP) b_fetch(s2 % HRING, s2 >> 2, chunk * 4 + (s2 & 3));
+                    if (s2 < NSTEP) b_fetch(s2 % HRING, s2 >> 2, chunk * 4 + (s2 & 3));
                     else if (has_next) b_fetch(s2 % HRING, (s2 - NSTEP) >> 2, (chunk + 1) * 4 + ((s2 - NSTEP) & 3));
                 }
                 HP3D_SCHED_BARRIER();          // the prefetches are issued BEFORE this step's MFMAs: a whole step of latency cover
@@ -330,17 +326,6 @@ void conv_h16_kernel(const ConvParams p) {
         //      every global store is 16 B per lane with one pixel's couts contiguous (the pooled form takes the max of the four
         //      pixels' half vectors on the way: rounding is monotonic, so max-then-round == round-then-max).
         //      Buffer stores with 32-bit offsets inside the image; an invalid lane gets an out-of-range offset and is dropped.
-        if (HP3D_H16_ABL & 1) {                 // all accumulators stay live
-            float t = 0.f;
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t += acc[mt][nt][r];
-            if (t == 12345.f) p.out[0] = t;
-            continue;
-        }
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC((hp3d_f16*)p.out + (size_t)b * Hs * Ws * p.out_cs,
                                                  (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 2u);
         const int px_b = p.out_cs * 2;                                       // bytes per output pixel

@@ -23,9 +23,6 @@
 //   * next tap's weights are prefetched into registers while the current tap computes; one
 //     barrier per tap; two workgroups per CU hide the remaining staging latency.
 #include "hp3d_common.h"
-#ifndef HP3D_MFMA_ABL
-#define HP3D_MFMA_ABL 0          // timing ablations (scripts/build_variant.sh); any non-zero value computes wrong results
-#endif
 #include <cstdio>
 #include <cstdlib>
 
@@ -169,7 +166,6 @@ void conv_mfma_kernel(const ConvParams p) {
     }
     auto w_dma = [&](int tp, int ch, int bufidx) {
         const int soff = w_base_b + tp * tap_stride_b + ch * chunk_stride_b;          // scalar
-        if (HP3D_MFMA_ABL & 2) return;
 #pragma unroll
         for (int v = 0; v < C::WVEC; ++v)
             HP3D_BUFFER_LDS16(wrsrc, wbuf + bufidx * C::WBUF_FLOATS + (v * NWAVES + wave_u) * 256, wvoff[v], soff, lane);
@@ -177,7 +173,6 @@ void conv_mfma_kernel(const ConvParams p) {
     f32x4 fa[2][MT], fb[2][NT];
     const int bbase = (wn * NT) * 256 + lane * 4;
     auto load_frags = [&](int set, int toff, int g, int bufidx) {
-        if (HP3D_MFMA_ABL & 4) { asm volatile("" : "+v"(fa[set][0]), "+v"(fb[set][0])); return; }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) fa[set][mt] = *(const f32x4*)(patch + abase[mt] + (toff + g * 8));
 #pragma unroll
@@ -218,23 +213,21 @@ void conv_mfma_kernel(const ConvParams p) {
         HP3D_SCHED_BARRIER();
         // hipcc (ROCm 7.2) does NOT carry a pending LDS-DMA across the loop back-edge into the barrier's
         // wait: retire this wave's DMA of W(it+1) explicitly before the rendezvous.
-#if !(HP3D_MFMA_ABL & 1)
         HP3D_WAIT_VMCNT0();
         __syncthreads();
-#endif
         if (it + 2 < total) {
             const int tp2 = (tap + 2 < TAPS) ? tap + 2 : tap + 2 - TAPS;     // TAPS == 1: handled below
             const int ch2 = (tap + 2 < TAPS) ? chunk : chunk + 1;
             if (TAPS == 1) w_dma(0, chunk + 2, buf2); else w_dma(tp2, ch2, buf2);
         }
-        if (chunk_end && has_next && !(HP3D_MFMA_ABL & 8)) patch_fetch(chunk + 1);
+        if (chunk_end && has_next) patch_fetch(chunk + 1);
         HP3D_SCHED_BARRIER();
         load_frags(1, toff, 3, buf);
         mfma_group(0);
         if (has_next && !chunk_end) load_frags(0, tap_off(tap + 1), 0, buf1);
         mfma_group(1);
         HP3D_SCHED_BARRIER();
-        if (chunk_end && has_next && !(HP3D_MFMA_ABL & 8)) {
+        if (chunk_end && has_next) {
             __syncthreads();          // every wave is done reading this chunk's patch
             patch_commit();
             __syncthreads();

@@ -31,9 +31,6 @@
 //     of 196 multiplies per 2x2 outputs, 45 steps per item.
 #include "hp3d_common.h"
 #include <cstdlib>
-#ifndef HP3D_WINO_ABL
-#define HP3D_WINO_ABL 0          // timing ablations (scripts/history/gpu_abl.sh); any non-zero value computes wrong results
-#endif
 #include <cstring>
 #include <type_traits>
 
@@ -146,13 +143,8 @@ void conv_wino_kernel(const ConvParams p) {
 
     f32x4 d[16];
     auto window_fetch = [&](int soff) {
-#if HP3D_WINO_ABL & 2
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { f32x4 t = {1.f + soff, 2.f, 3.f, 4.f}; asm volatile("" : "+v"(t)); d[e] = t; }
-#else
 #pragma unroll
         for (int e = 0; e < 16; ++e) d[e] = HP3D_BUFFER_LOAD16(irsrc, wv[e], soff);
-#endif
     };
     auto transform_commit = [&](int buf) {
         // B^T d B with B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
@@ -324,9 +316,7 @@ void conv_wino_kernel(const ConvParams p) {
                 if (pl == 12) transform_commit(cur ^ 1);      // its LDS writes land under planes 13..15
             }
             HP3D_SCHED_BARRIER();
-#if !(HP3D_WINO_ABL & 1)
             __syncthreads();             // V[cur^1] complete, V[cur] free
-#endif
             cur ^= 1;
             sub_cur = nsub_;             // the block of the step that runs next (this item's or the next item's first)
         };

@@ -410,9 +410,6 @@ void seg_softmax_kernel(const float* large, int B, int H, int W, unsigned char* 
 // O_0 = {seed};  O_{j+1} = det AND dilate21x21(O_j), j < max(H,W)//10 passes, bit-packed in LDS;
 // stops early at a fix-point (exactly equivalent: the iteration is deterministic).
 // Row r of the bitmap is WW = ceil(W/32) words; pixel x is bit x%32 of word x/32.
-#ifndef HP3D_MG_ABL
-#define HP3D_MG_ABL 0           // timing ablations of mask_grow (wrong results)
-#endif
 constexpr int MG_R = 12;          // rows per thread in the vertical pass of mask_grow
 HP3D_KERNEL(1024)
 void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, int H, int W, int empty_fltmax,
@@ -454,12 +451,11 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
     if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_cmin = 0x7fffffff; s_cmax = -1; }
     __syncthreads();
 
-    const int num_passes = (HP3D_MG_ABL & 1) ? 0 : max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
+    const int num_passes = max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
     for (int pass = 0; pass < num_passes; ++pass) {
         if (tid == 0) s_changed = 0;
         // horizontal dilation, radius 10
         for (int w = tid; w < NWORD; w += nthr) {
-            if (HP3D_MG_ABL & 2) { tmp[w] = obj[w]; continue; }
             const int wx = w % WW;
             // neighbours read unconditionally (clamped index) and masked afterwards: three independent LDS reads in flight
             const unsigned lo_r = obj[w > 0 ? w - 1 : 0], mid_r = obj[w], hi_r = obj[w + 1 < NWORD ? w + 1 : w];
@@ -479,7 +475,7 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
         // 2.7 LDS reads per output instead of 21 + 21
         int changed = 0;
         const int nseg = (H + MG_R - 1) / MG_R;
-        for (int u = tid; u < ((HP3D_MG_ABL & 4) ? 0 : nseg * WW); u += nthr) {
+        for (int u = tid; u < nseg * WW; u += nthr) {
             const int seg = u / WW, wx = u - seg * WW;
             const int y0 = seg * MG_R;
             unsigned v[MG_R + 20];
@@ -521,7 +517,7 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
         __syncthreads();
         const int any = s_changed;
         __syncthreads();
-        if (!any && !(HP3D_MG_ABL & 8)) break;
+        if (!any) break;
     }
 
     // bounding box (calc_center_bb): "x" = row index, "y" = column index

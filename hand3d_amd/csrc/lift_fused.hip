@@ -308,14 +308,6 @@ int lift_fused_launch(const LiftFusedParams& pin, hipStream_t s) {
     }
     int nwg = hp3d_num_cus() / 2 > 0 ? hp3d_num_cus() / 2 : 1;
     p.phase_lo = 0; p.phase_hi = 8;
-#ifdef HP3D_TUNING      // tuning builds only: a stray environment variable must not change (or corrupt) a deployment's results
-    if (const char* e = getenv("HP3D_LIFT_WGS")) { const int v = atoi(e); if (v > 0) nwg = v; }
-    if (const char* e = getenv("HP3D_LIFT_ABL")) {          // timing ablations (wrong results): 1 = no grid barriers, 2 = barriers only
-        if (atoi(e) == 1) p.towers |= 256;
-        if (atoi(e) == 2) p.B = 0;
-        if (atoi(e) >= 10) p.phase_hi = atoi(e) - 10;       // 10 + n: phases 0..n only
-    }
-#endif
     const int cap = resident[dev] > hp3d_num_cus() ? resident[dev] - hp3d_num_cus() / 8 : resident[dev] * 7 / 8;
     if (nwg > cap) nwg = cap > 0 ? cap : 1;
     HP3D_LAUNCH(lift_fused_kernel, dim3(nwg), dim3(LF_THREADS), LF_SMEM_BYTES, s, p);

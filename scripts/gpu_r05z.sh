@@ -1,0 +1,16 @@
+#!/bin/bash
+# round 5, final visit of the committed tree: the whole GPU suite + rocprofv3 stats + PMC passes + bench with layers (scripts/gpu_round.sh),
+# smoke(), the config-5 line, and the driver's exact command (-> profiles/r05_* via scripts/summarize_prof.py and scripts/make_configs_md.py)
+TAG=${1:-r05}
+bash scripts/gpu_round.sh $TAG pmc
+OUT=gpurun_out/$TAG
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -3 $OUT/smoke.log
+timeout 300 python bench.py --dtype f16 --batch 128 --height 480 --width 640 --steps 3 --warmup 2 --cpu-seconds 0 --no-host-path --no-other-configs --layers > $OUT/bench_c5_f16.json 2> $OUT/bench_layers_c5_f16.txt; echo "c5 exit $?"
+( time timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err ) 2> $OUT/bench_driver_time.txt; echo "driver cmd exit $?"; tail -3 $OUT/bench_driver_time.txt
+python -c "
+import json
+d=json.loads(open('$OUT/bench_driver.json').read().strip().splitlines()[-1])
+print('driver line', d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('traffic'), 'other_configs wall', d.get('other_configs_wall_s'))
+for c in d.get('other_configs', []): print('  ', c.get('config'), c.get('images_per_s'), c.get('ms_per_step'), c.get('executed_frac_of_dense_peak'), c.get('error'))
+c=json.loads(open('$OUT/bench_c5_f16.json').read().strip().splitlines()[-1]); print('c5', c['value'], c['ms_per_step'], c['roofline']['frac'], c['roofline'].get('traffic'))
+"

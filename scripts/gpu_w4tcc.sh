@@ -12,7 +12,7 @@ import csv,glob,collections,re
 agg=collections.OrderedDict()
 for f in sorted(glob.glob('$OUT/*/p_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        m=re.search(r'(conv_wino[24]?_kernel<[^>]*>)', r['Kernel_Name'])
+        m=re.search(r'(conv_wino[247]?_kernel(?:<[^>]*>)?)', r['Kernel_Name'])
         if not m: continue
         d=agg.setdefault(m.group(1),collections.defaultdict(list))
         d[r['Counter_Name']].append(float(r['Counter_Value']))

@@ -3,7 +3,7 @@ import collections, csv, glob, re, sys
 agg = collections.OrderedDict()
 for f in sorted(glob.glob(sys.argv[1] + '/*/p_counter_collection.csv')):
     for r in csv.DictReader(open(f)):
-        m = re.search(r'(conv_wino[24]?_kernel<[^>]*>)', r['Kernel_Name'])
+        m = re.search(r'(conv_wino[247]?_kernel(?:<[^>]*>)?)', r['Kernel_Name'])
         if not m:
             continue
         d = agg.setdefault(m.group(1), collections.defaultdict(list))

@@ -94,7 +94,7 @@ def main():
         except Exception:
             wl_src = {}
     lines = ['# rocprofv3 summary %s' % tag, '',
-             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path --option streams=1`',
+             'command: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py --gpus 1 --steps 10 --warmup 3 --cpu-seconds 0 --no-host-path --no-other-configs --option streams=1`',
              '(one HIP stream, so that kernel durations are not inflated by the overlap the default two-stream mode is there to create;',
              ' the bench line below is the DEFAULT command, whose roofline block comes from its own serial, event-timed pass)',
              '(PMC: separate `--kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, `--steps 2 --warmup 1`)', '',

@@ -117,6 +117,9 @@ __device__ __forceinline__ void w7_at(T m0, T m1, T m2, T m3, T m4, T m5, T m6, 
 // quad swizzle of a V row: window slot (hy, hx) stores channel quad q at position q ^ 2 (hy & 1)
 __device__ __forceinline__ int w7_swz_row(int hy) { return (hy & 1) << 1; }
 
+// SPLITK (under-filled launches, i.e. small batches): an item additionally owns a contiguous range of the 16-channel chunks and stores its RAW 4x4 sums
+// (the output transform is linear) into `[ksplit][B*Ho*Wo][Cout]`; conv_splitk_reduce adds the slices in order, + bias, activation (deterministic).
+template <bool SPLITK>
 HP3D_KERNEL2(256, 1)
 void conv_wino7_kernel(const ConvParams p) {
     HP3D_DYN_SMEM(V);
@@ -129,7 +132,8 @@ void conv_wino7_kernel(const ConvParams p) {
     const int TXn = p.tiles_x, TYn = p.tiles_y;
     const int bxn = (TXn + 3) >> 2, byn = (TYn + 3) >> 2, per_img = bxn * byn;
     const int nblocks = p.B * per_img, ncy = p.Cout / W7_COUTS;
-    const int nitems = nblocks * ncy;
+    const int per_split = nblocks * ncy;
+    const int nitems = per_split * (SPLITK ? p.ksplit : 1);
     // item -> (cout block, tile block): XCD-affine (workgroup ids go round-robin over the 8 XCDs; the cout blocks of one tile block run on ONE XCD,
     // so its windows cross the fabric once), as conv_wino4.hip's item_decode
     auto item_decode = [&](int r, int& cy_, int& tb_) {
@@ -150,14 +154,14 @@ void conv_wino7_kernel(const ConvParams p) {
         by = r / bxn;
         bx = r - by * bxn;
     };
-    auto table_write = [&](int tb, int parity) {
+    auto table_write = [&](int tb, int parity, int kz) {
         if (tid < W7_TILES) {
             int img, by, bx;
             block_decode(tb, img, by, bx);
             const int ty = 4 * by + (tid >> 2), tx = 4 * bx + (tid & 3);
             int off = -1, fl = 0;
             if (ty < TYn && tx < TXn) {
-                off = ((img * p.Ho + 4 * ty) * p.Wo + 4 * tx) * p.out_cs;
+                off = (((SPLITK ? kz * p.B + img : img) * p.Ho + 4 * ty) * p.Wo + 4 * tx) * p.out_cs;
                 fl = min(4, p.Ho - 4 * ty) | (min(4, p.Wo - 4 * tx) << 4);
             }
             tinfo[parity * 2 * W7_TILES + tid] = off;
@@ -185,7 +189,7 @@ void conv_wino7_kernel(const ConvParams p) {
         for (int c = 0; c < 7; ++c) co[c] = (unsigned)(wx0 + c) < (unsigned)p.W ? c * cs4 : COL_OOR;
     };
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)cs4);
-    [[maybe_unused]] const unsigned out_bytes = (unsigned)p.B * (unsigned)(p.Ho * p.Wo) * (unsigned)p.out_cs * 4u;
+    [[maybe_unused]] const unsigned out_bytes = (unsigned)(SPLITK ? p.ksplit * p.B : p.B) * (unsigned)(p.Ho * p.Wo) * (unsigned)p.out_cs * 4u;
 
     f32x2 d[W7_NP];
     auto window_load = [&](int e, int soff) { d[e] = HP3D_BUFFER_LOAD8(irsrc, (int)((unsigned)ro[e / 7] + (unsigned)co[e % 7]), soff); };
@@ -242,17 +246,19 @@ void conv_wino7_kernel(const ConvParams p) {
 
     for (int item = blockIdx.x, k = 0; item < nitems; item += (int)gridDim.x, ++k) {
         int cy, tblock;
-        item_decode(item, cy, tblock);
+        const int kz = SPLITK ? HP3D_READFIRSTLANE(item / per_split) : 0;
+        item_decode(SPLITK ? item - kz * per_split : item, cy, tblock);
         cy = HP3D_READFIRSTLANE(cy);
         tblock = HP3D_READFIRSTLANE(tblock);
+        const int c0 = SPLITK ? (kz * nchunks) / p.ksplit : 0, c1 = SPLITK ? ((kz + 1) * nchunks) / p.ksplit : nchunks;      // this item's chunks
         const int cyoff = (cy * (W7_COUTS / 16) + wave) * 1024;          // byte offset of this wave's cout group inside a product's block
         if (k) __syncthreads();                   // the previous item's epilogue has read its tile table; its last chunk's V buffer is free
         loader_setup(tblock);
-        table_write(tblock, 0);
-        // ---- prologue: chunk 0's windows -> V[0], the first ring of weight fragments, accumulators = 0
+        table_write(tblock, 0, kz);
+        // ---- prologue: the first chunk's windows -> V[0], the first ring of weight fragments, accumulators = 0
 #pragma unroll
-        for (int e = 0; e < W7_NP; ++e) window_load(e, 0);
-        wsb = cyoff;
+        for (int e = 0; e < W7_NP; ++e) window_load(e, c0 * (W7_CK * 4));
+        wsb = cyoff + c0 * (W7_SEQ * entry_stride_b);
 #pragma unroll
         for (int t = 0; t < W7_RING; ++t) b_fetch(t);
 #pragma unroll
@@ -263,10 +269,10 @@ void conv_wino7_kernel(const ConvParams p) {
         __syncthreads();
         int cur = 0;
 
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const bool lastc = chunk + 1 == nchunks;
+        for (int chunk = c0; chunk < c1; ++chunk) {
+            const bool lastc = chunk + 1 == c1;
             const int wsoff = (lastc ? chunk : chunk + 1) * (W7_CK * 4);      // (the last chunk re-reads its own windows: harmless, never used)
-            // (weight fragments requested past the last chunk lie outside the buffer: they read as 0 and are never used)
+            // (weight fragments requested past this item's last chunk are the next chunk's, or lie outside the buffer and read as 0: never used)
             a_bases(cur);
             a_fetch(0);
             a_fetch(1);
@@ -321,9 +327,9 @@ void conv_wino7_kernel(const ConvParams p) {
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3");
 #endif
         const int cout = cy * W7_COUTS + wave * 16 + ln;
-        const float bias = p.bias[cout];
+        const float bias = SPLITK ? 0.f : p.bias[cout];                  // (raw sums: bias and activation happen in the reduce)
         const bool cok = cout < p.cout_store;
-        const float slope = p.act ? HP3D_LEAKY_SLOPE : 1.f;
+        const float slope = (!SPLITK && p.act) ? HP3D_LEAKY_SLOPE : 1.f;
         const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, out_bytes);
         const int srow = p.Wo * p.out_cs * 4, scol = p.out_cs * 4;
         const bool full = HP3D_OPAQUE_SGPR((((p.Ho | p.Wo) & 3) == 0) ? 1 : 0) != 0;
@@ -412,27 +418,51 @@ void wino7_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int
 }
 
 // 1: the layer can run here -- 7x7 / stride 1, Cin % 16 == 0, Cout % 64 == 0, offsets below 2^30 / 2^31 bytes; *items (may be NULL) = work items of the launch
-int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items) {
+// *ksplit (may be NULL): the channel split that fills the chip when the launch alone does not (1 = none; at most one split per 16-channel chunk)
+int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items, int* ksplit) {
     if (items) *items = 0;
+    if (ksplit) *ksplit = 1;
     if (k != 7 || stride != 1 || Cin % W7_CK || Cout % W7_COUTS) return 0;
     if ((long)B * Ho * Wo * in_cs * 4 >= (1L << 30) || (long)B * Ho * Wo * out_cs * 4 >= (1L << 31)) return 0;
     const long blocks = (long)B * (((Ho + 3) / 4 + 3) / 4) * (((Wo + 3) / 4 + 3) / 4);
-    if (items) *items = blocks * (Cout / W7_COUTS);
+    const long n = blocks * (Cout / W7_COUTS);
+    if (items) *items = n;
+    const int slots = hp3d_num_cus(), nchunks = Cin / W7_CK;
+    if (ksplit && n * 8 < (long)slots * 5) {
+        int ks = (int)(slots / n);
+        if (ks > nchunks) ks = nchunks;
+        if (ks >= 2 && (long)ks * B * Ho * Wo * Cout * 4 < (1L << 31)) *ksplit = ks;
+    }
     return 1;
 }
 
+template <bool SPLITK>
+static void wino7_launch_t(const ConvParams& p, hipStream_t s) {
+    static bool attr_done[64] = {};
+    auto k = conv_wino7_kernel<SPLITK>;
+    if (hp3d_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, W7_SMEM_BYTES);
+    const long items = (long)p.B * ((p.tiles_x + 3) / 4) * ((p.tiles_y + 3) / 4) * (p.Cout / W7_COUTS) * (SPLITK ? p.ksplit : 1);
+    const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU
+    dim3 grid((unsigned)(items < slots ? items : slots));
+    HP3D_LAUNCH(k, grid, dim3(256), W7_SMEM_BYTES, s, p);
+}
+
+// pin.ksplit > 1: pin.out must be the partial-sum scratch [ksplit][B*Ho*Wo][Cout] with out_cs = cout_store = Cout; the caller runs
+// conv_splitk_reduce afterwards (bias + activation happen there).
 int conv_wino7_launch(const ConvParams& pin, hipStream_t s) {
-    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || (long)pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
-    if (pin.Cout % W7_COUTS || pin.Cin % W7_CK || pin.ksplit > 1) return -1;
+    const long kso = pin.ksplit > 1 ? pin.ksplit : 1;
+    if ((long)pin.B * pin.H * pin.W * pin.in_cs * 4 >= (1L << 30) || kso * pin.B * pin.Ho * pin.Wo * pin.out_cs * 4 >= (1L << 31)) return -1;
+    if (pin.Cout % W7_COUTS || pin.Cin % W7_CK) return -1;
     ConvParams p = pin;
     p.tiles_x = (p.Wo + 3) / 4;
     p.tiles_y = (p.Ho + 3) / 4;
-    static bool attr_done[64] = {};
-    if (hp3d_first_use_on_device(attr_done))
-        (void)hipFuncSetAttribute((const void*)conv_wino7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, W7_SMEM_BYTES);
-    const long items = (long)p.B * ((p.tiles_x + 3) / 4) * ((p.tiles_y + 3) / 4) * (p.Cout / W7_COUTS);
-    const int slots = hp3d_num_cus();                     // persistent grid: one workgroup per CU
-    dim3 grid((unsigned)(items < slots ? items : slots));
-    HP3D_LAUNCH(conv_wino7_kernel, grid, dim3(256), W7_SMEM_BYTES, s, p);
+    if (p.ksplit > 1) {
+        if (p.ksplit > p.Cin / W7_CK || p.out_cs != p.Cout) return -1;
+        wino7_launch_t<true>(p, s);
+    } else {
+        p.ksplit = 1;
+        wino7_launch_t<false>(p, s);
+    }
     return 0;
 }

@@ -244,6 +244,7 @@ struct hp3d_ctx {
     float *bufA = nullptr, *bufB = nullptr, *col = nullptr;
     size_t col_floats = 0;
     int capB = 0;
+    int sideB = 0;             // batch the FC buffers hold when this context is only the side tower of an overlapped lifting stage (ensure_side_tower)
     float *d_image = nullptr, *d_hs = nullptr, *d_large = nullptr, *d_crop = nullptr, *d_center = nullptr,
           *d_scale = nullptr, *d_cropsize = nullptr, *d_kpmap = nullptr, *d_coord = nullptr, *d_mask = nullptr,
           *d_segsmall = nullptr, *d_concat = nullptr, *d_sm[3] = {nullptr, nullptr, nullptr}, *d_can = nullptr,
@@ -278,6 +279,8 @@ struct hp3d_ctx {
     int use_h16 = 1;           // half-precision 3x3 trunk layers on conv_h16.hip (option "f16_impl" = "h16" | "mfma")
     int h16_k7k1 = 1;          // ... and the 7x7 / 1x1 layers with >= 64 couts on its single-buffer forms (option "f16_k7k1" = 0 | 1)
     int wino_splitk = 1;       // Winograd layers that under-fill the chip split their channel steps (option "wino_splitk")
+    int lift_overlap = 1;      // option "lift_overlap": the two towers of the unfused lifting stage on two streams (ViewpointNet on the child context's)
+    long lift_overlap_calls = 0;
     int use_lift_fused = -1;   // the lifting stage as one launch (lift_fused.hip): -1 auto (B <= 4), 0 never, 1 always (option "lift_fused")
     unsigned* d_liftbar = nullptr;
     unsigned* h_lifterr = nullptr;     // mapped host word: lift_fused.hip's grid barrier timed out (results of that launch are invalid)
@@ -296,6 +299,8 @@ struct hp3d_ctx {
     long conv_pw2_launches = 0;
     int use_wino7 = -1;        // conv_wino7.hip (the 7x7 layers as Winograd F(4x4,4x4)), option "wino7": -1 auto (launches that fill the chip), 0 never, 1 wherever eligible
     long conv_wino7_launches = 0;
+    int wino7_ksplit = 0;      // option "wino7_ksplit": 0 = auto (conv_wino7_eligible's choice for under-filled launches), N = that many channel splits (tests, tuning)
+    long conv_wino7_split_launches = 0;
     long conv_wino4_tail_launches = 0;
     long conv_wino4_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino4.hip
     long conv_wino2_launches = 0;                   // hp3d_get_counter: layers that went to conv_wino2.hip
@@ -455,6 +460,7 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->d_seed, (size_t)B * 2));
         CHK(dev_realloc(ctx, &ctx->d_keys, (size_t)B));
         ctx->capB = B;
+        ctx->sideB = B;
     }
     return 0;
 }
@@ -564,6 +570,12 @@ static int wino2_ks_probe(hp3d_ctx* ctx, const ConvL& l, int Ho, int Wo, int B, 
 // in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
 // f16 = 1 (trunk nets after hp3d_finalize_weights(dtype=1)): `in` / `out` hold halves (except the raw image of
 // conv1_1 and out_f32 heads); in_cs / out_cs are then counted in ELEMENTS of the respective tensor.
+static int wino7_ks_override(const hp3d_ctx* ctx, int ks, int cin_pad, long out_floats) {        // option "wino7_ksplit"
+    if (ctx->wino7_ksplit <= 0 || !ctx->wino_splitk) return ks;
+    ks = std::min(ctx->wino7_ksplit, cin_pad / 16);
+    return (ks >= 2 && ks * out_floats * 4 < (1L << 31)) ? ks : 1;
+}
+
 int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, int H, int W, float* out, int out_cs,
              int pool, int* Ho_out, int* Wo_out, int f16 = 0, int out_f32 = 0) {
     int Ho, Wo, pt, pl;
@@ -578,10 +590,14 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
                                                                                  ctx->wino_splitk ? &wino_ks : nullptr) : 0;
     // 7x7 layers (PoseNet2D's refinement units): Winograd F(4x4,4x4) over the filter's four 4x4-tap blocks when the launch fills the chip
     // (one work item = a 4x4 tile block x 64 couts, no channel split: 160 of 256 CUs busy already beats the split nine-block form + its reduce)
+    // (under-filled launches -- small batches -- split the 16-channel chunks over workgroups and add the raw sums in a reduce launch, like the other
+    //  Winograd kernels: option "wino_splitk")
     long items7 = 0;
+    int ks7 = 1;
     const bool take7 = ctx->use_wino && ctx->use_wino7 && !f16 && l.ww7_off && !pool && !ctx->conv_naive &&
-        conv_wino7_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, &items7) &&
-        (ctx->use_wino7 == 1 || items7 >= (long)hp3d_num_cus() * 5 / 8);
+        conv_wino7_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, &items7, ctx->wino_splitk ? &ks7 : nullptr) &&
+        ((ks7 = wino7_ks_override(ctx, ks7, l.cin_pad, (long)B * Ho * Wo * l.cout_pad)), true) &&
+        (ctx->use_wino7 == 1 || items7 >= (long)hp3d_num_cus() * 5 / 8 || (ks7 > 1 && ctx->use_wino7 == -1 && !ctx->two_streams_live));
     if (take7) {
         ConvParams p;
         p.in = in; p.wpk = ctx->blob + l.ww7_off; p.bias = ctx->blob + l.b_off; p.out = out;
@@ -589,10 +605,27 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
         p.cout_store = std::min(l.cout_pad, out_cs);
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
-        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
-        ProfScope ps(ctx, l.name, "conv_wino7_f4x4_4x4_as7x7", flops, bytes);
-        if (conv_wino7_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,4x4)): launch refused");
+        p.act = l.relu; p.im2col = 0; p.ksplit = ks7; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
+        if (ks7 > 1) {
+            const size_t need = (size_t)ks7 * B * Ho * Wo * l.cout_pad;
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+            p.out = ctx->col; p.out_cs = l.cout_pad; p.cout_store = l.cout_pad;
+        }
+        {
+            ProfScope ps(ctx, l.name, ks7 > 1 ? "conv_wino7_f4x4_4x4_as7x7_splitk" : "conv_wino7_f4x4_4x4_as7x7", flops, bytes);
+            if (conv_wino7_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,4x4)): launch refused");
+        }
+        if (ks7 > 1) {
+            ProfScope ps(ctx, l.name, "conv_splitk_reduce", 0.0, 4.0 * (ks7 + 1) * B * Ho * Wo * l.cout_pad);
+            conv_splitk_reduce_launch(ctx->col, ks7, (long)B * Ho * Wo, l.cout_pad, ctx->blob + l.b_off, l.relu, out, out_cs,
+                                      std::min(l.cout_pad, out_cs), ctx->stream);
+        }
         ++ctx->conv_wino7_launches;
+        ctx->conv_wino7_split_launches += ks7 > 1;
         HIPCHK(ctx, hipGetLastError());
         if (Ho_out) *Ho_out = Ho;
         if (Wo_out) *Wo_out = Wo;
@@ -1034,6 +1067,26 @@ int run_lift_fused(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int
     return 0;
 }
 
+int kid_sync_state(hp3d_ctx* ctx);
+
+// The child context's share of an overlapped lifting stage: ViewpointNet's activations ([B,32,32,64] is the largest), its FC buffers
+// and split-K partial sums.  (A later two-stream call grows the same arena through ensure_arena.)
+int ensure_side_tower(hp3d_ctx* k, int B) {
+    const size_t act = (size_t)B * 32 * 32 * 64;
+    if (act > k->act_floats) {
+        CHK(dev_realloc(k, &k->bufA, act));
+        CHK(dev_realloc(k, &k->bufB, act));
+        k->act_floats = act;
+    }
+    if (B > k->sideB) {
+        CHK(dev_realloc(k, &k->d_fc1, (size_t)B * 512));
+        CHK(dev_realloc(k, &k->d_fc2, (size_t)B * 512));
+        CHK(dev_realloc(k, &k->d_fcpart, (size_t)B * 17 * 512 + (size_t)B * 33 * 256));
+        k->sideB = B;
+    }
+    return 0;
+}
+
 int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant) {
     const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
     const bool fused = !ctx->conv_naive && (ctx->use_lift_fused == 1 || (ctx->use_lift_fused < 0 && B <= 4)) &&
@@ -1041,8 +1094,35 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
     if (fused) {
         CHK(run_lift_fused(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, do_rot));
     } else {
-        CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
-        if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
+        // The two towers share only their input (nets/ColorHandPose3DNetwork.py:231-235): 12 + 12 dependent launches of 13-25 us each that
+        // leave most of the chip idle.  ViewpointNet runs on the child context's stream (own activations and partial sums, shared weights)
+        // beside PosePrior on this one; the epilogue below waits for both.  Not while profiling per launch, replaying a graph, or when
+        // this context is (or is busy with) the second stream of a two-stream call.
+        bool side = false;
+#ifndef HP3D_EMU
+        side = do_rot && ctx->lift_overlap && !ctx->profiling && !ctx->use_graph && !ctx->conv_naive && !ctx->shared_weights &&
+               !ctx->two_streams_live && kid_sync_state(ctx) == 0 && ensure_side_tower(ctx->kid, B) == 0;
+        if (side) {
+            hp3d_ctx* k = ctx->kid;
+            HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+            HIPCHK(ctx, hipStreamWaitEvent(k->stream, ctx->ev_fork, 0));
+            struct Join {       // recorded and waited for on every exit path (as in infer_full_chunked)
+                hp3d_ctx *p, *k;
+                ~Join() {
+                    if (hipEventRecord(p->ev_join, k->stream) == hipSuccess) (void)hipStreamWaitEvent(p->stream, p->ev_join, 0);
+                    else (void)hipStreamSynchronize(k->stream);
+                }
+            } join{ctx, k};
+            const int rc = run_viewpoint(k, sm32, hs, B, ctx->d_u);
+            if (rc != 0) { set_error(ctx, k->err.c_str()); return rc; }
+            CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
+            ++ctx->lift_overlap_calls;
+        }
+#endif
+        if (!side) {
+            CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
+            if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
+        }
     }
     if (variant == HP3D_VARIANT_LOCAL)     // bone_rel_trafo_inv (nets/PosePriorNetwork.py:70-75)
         bone_rel_inv_launch(ctx->d_can, B, ctx->d_coord, ctx->stream);
@@ -1232,7 +1312,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1605,12 +1685,14 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "lift_overlap" && (v == "0" || v == "1")) { ctx->lift_overlap = v == "1"; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
         return 0;
     }
     if (k == "pw2" && (v == "0" || v == "1" || v == "force")) { ctx->use_pw2 = v == "0" ? 0 : v == "1" ? 1 : 2; return 0; }
+    if (k == "wino7_ksplit") { ctx->wino7_ksplit = v == "auto" ? 0 : std::max(0, atoi(v.c_str())); return 0; }
     if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
@@ -2079,8 +2161,10 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
+    int op_ks7 = 1;
     if (ctx->use_wino && ctx->use_wino7 == 1 && !ctx->conv_naive && k == 7 && !pool && Cout % 64 == 0 &&
-        conv_wino7_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, nullptr)) {
+        conv_wino7_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, nullptr, ctx->wino_splitk ? &op_ks7 : nullptr)) {
+        op_ks7 = wino7_ks_override(ctx, op_ks7, l.cin_pad, (long)B * Ho * Wo * Cout);
         // option "wino7" = "1": the F(4x4,4x4) form of a 7x7 filter (conv_wino7.hip)
         const size_t wn = wino7_packed_floats(l.cin_pad, l.cout_pad);
         std::vector<float> pw(wn + l.cout_pad, 0.f);
@@ -2092,9 +2176,16 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
         p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
-        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
+        p.act = act; p.im2col = 0; p.ksplit = op_ks7; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 4;
+        float* d_part7 = nullptr;
+        if (op_ks7 > 1) {          // under-filled launch: raw partial sums per channel split, then the deterministic reduce
+            d_part7 = S.alloc<float>((size_t)op_ks7 * B * Ho * Wo * Cout); NN(ctx, d_part7);
+            p.out = d_part7;
+        }
         if (conv_wino7_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,4x4)): launch refused");
+        if (op_ks7 > 1) conv_splitk_reduce_launch(d_part7, op_ks7, (long)B * Ho * Wo, Cout, d_pk + wn, act, d_out, Cout, Cout, ctx->stream);
         ++ctx->conv_wino7_launches;
+        ctx->conv_wino7_split_launches += op_ks7 > 1;
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
         return finish_op(ctx);
@@ -2332,9 +2423,11 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "lift_overlap_calls") { *value = ctx->lift_overlap_calls; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }
     if (k == "conv_pw2_launches") { *value = ctx->conv_pw2_launches + (ctx->kid ? ctx->kid->conv_pw2_launches : 0); return 0; }
+    if (k == "conv_wino7_split_launches") { *value = ctx->conv_wino7_split_launches + (ctx->kid ? ctx->kid->conv_wino7_split_launches : 0); return 0; }
     if (k == "conv_wino7_launches") { *value = ctx->conv_wino7_launches + (ctx->kid ? ctx->kid->conv_wino7_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }

@@ -319,7 +319,7 @@ size_t conv_wino4_tail_floats();
 // packed filters [chunk Cin/16][169 non-zero (block, plane) products][Cout/16][q][n][e]
 size_t wino7_packed_floats(int cin_pad, int cout_pad);
 void wino7_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
-int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items);
+int conv_wino7_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, long* items, int* ksplit);
 int conv_wino7_launch(const ConvParams& p, hipStream_t s);
 // conv_pw2.hip: two 1x1 convolutions as one launch (the head pairs of both trunks): out = act2((act1(x W1 + b1)) W2 + b2); x [npix, >= 128 ch],
 // W1 / W2 in conv_mfma.hip's packed order (pack_conv, k = 1), hidden width H a multiple of 128, 32 padded output channels

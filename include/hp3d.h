@@ -102,7 +102,11 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            16 outputs, the transformed input shared by the four blocks, one work item = 16 tiles x 64 couts with no channel
  *                            split) when the launch fills the chip (>= 160 work items: B >= 20 on the 32 x 32 score maps) | never (the
  *                            nine-3x3-block form on conv_wino4.hip / conv_wino2.hip) | whenever the shape allows (tests).  Float32 throughout,
- *                            the same rounding error as the nine-block form (profiles/r05_wino7_numerics.md);
+ *                            the same rounding error as the nine-block form (profiles/r05_wino7_numerics.md).  Launches below that fill
+ *                            (small batches) run the same kernel with the 16-channel chunks split over workgroups -- raw 4x4 sums per
+ *                            split, added in order by the reduce launch with bias and activation -- when "wino_splitk" = "1";
+ *          "wino7_ksplit" = "auto" (default) | N: the number of channel splits of such a launch (auto: CUs / work items, at most one split
+ *                            per chunk; N: tests and tuning, clamped to the number of chunks);
  *          "pw2"          = "1" (default) | "0" | "force": the 1x1 head pairs of both trunks (conv6_1 + conv6_2; conv5_1 + conv5_2, conv6_6 + conv6_7,
  *                            conv7_6 + conv7_7: ColorHandPose3DNetwork.py:160-161,202-203,213-214) as ONE launch each with the wide intermediate in
  *                            LDS (conv_pw2.hip, round 5) when the launch has a workgroup of 64 pixels per CU | two launches of the general kernel |
@@ -112,6 +116,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
  *                            MI355X (the second-stream child context grows its own), added in slice order by a small
  *                            reduce launch (deterministic; the summation order differs from the unsplit item: float32 rounding);
+ *          "lift_overlap" = "1" (default) | "0": the unfused lifting stage (batches above 4) runs ViewpointNet on a second stream beside
+ *                            PosePrior (the towers share only their input, ColorHandPose3DNetwork.py:231-235; 12 + 12 short dependent launches)
+ *                            | one after the other.  Same kernels, same results bit for bit;
  *          "lift_fused"   = "auto" (default) | "0" | "1": PosePrior + ViewpointNet + the lifting epilogue
  *                            (ColorHandPose3DNetwork.py:221-334) as ONE persistent launch with grid barriers (lift_fused.hip)
  *                            instead of 24 launches.  auto = for at most 4 images per call (the stage is latency-bound there:
@@ -271,7 +278,8 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
  * layers that ran on conv_h16.hip (option "f16_impl"); "conv_wino2_launches" = float32 layers that ran on conv_wino2.hip (option
  * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4"),
  * "conv_wino4_tail_launches" = those of them whose last round ran as channel slices (option "wino4_tail");
- * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7"); "conv_pw2_launches" = 1x1 layer pairs that ran as one launch (option "pw2");
+ * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7"), "conv_wino7_split_launches" = those of them in the channel-split form; "conv_pw2_launches" = 1x1 layer pairs that ran as one launch (option "pw2");
+ * "lift_overlap_calls" = lifting stages that ran their two towers on two streams (option "lift_overlap");
  * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */
 int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value);

@@ -392,6 +392,41 @@ def test_winograd_f4x4_4x4_for_7x7_filters_on_interpreter(emu_engine, case):
     assert y.shape == r.shape and e7 < 1e-4 and e7 < 3 * e9 + 2e-5, (e7, e9)
 
 
+@pytest.mark.parametrize("case", [(1, 16, 16, 48, 64, 1, 0), (1, 11, 14, 160, 64, 0, 3), (2, 20, 9, 64, 128, 1, 2), (3, 16, 16, 32, 64, 1, 7)],
+                         ids=lambda c: "B%d_%dx%d_%d-%d_a%d_ks%d" % c)
+def test_winograd_f4x4_4x4_channel_split_on_interpreter(emu_engine, case):
+    """conv_wino7.hip, SPLITK form (round 5, small batches: a B = 1 PoseNet2D 7x7 layer is 8 work items on 256 CUs): an item owns a contiguous
+    range of the 16-channel chunks and stores the RAW 4x4 sums of its range into [ksplit][B*Ho*Wo][Cout]; conv_splitk_reduce adds the slices
+    in order + bias + leaky-ReLU.  The automatic split of a one-item launch (3 interpreter CUs: 3 splits of 3 chunks), forced splits that cut
+    10 chunks unevenly (3+3+4), two cout blocks x two tile blocks, and a forced split larger than the number of chunks (clamped to 2).
+    Against the float64 oracle and the unsplit launch (another summation order: close, not equal); deterministic; the counter proves it ran."""
+    B, H, W, Cin, Cout, act, ks = case
+    rng = np.random.default_rng(sum(case) + 71)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    emu_engine.set_option('wino7', '1')
+    try:
+        emu_engine.set_option('wino_splitk', '0')
+        y1 = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+        emu_engine.set_option('wino_splitk', '1')
+        emu_engine.set_option('wino7_ksplit', str(ks) if ks else 'auto')
+        n0 = emu_engine.counter('conv_wino7_split_launches')
+        y = emu_engine.conv2d(x, w, b, 1, bool(act), False)
+        assert emu_engine.counter('conv_wino7_split_launches') == n0 + 1
+        assert np.array_equal(y, emu_engine.conv2d(x, w, b, 1, bool(act), False)), "not deterministic"
+    finally:
+        emu_engine.set_option('wino7', 'auto')
+        emu_engine.set_option('wino7_ksplit', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+    e, e1 = np.abs(y - r).max(), np.abs(y1 - r).max()
+    assert y.shape == r.shape and e < 1e-4 and e < 3 * e1 + 2e-5, (e, e1)
+    assert np.abs(y - y1).max() < 1e-4 and not np.array_equal(y, y1)
+
+
 def _near_tie_scoremaps(trial, rng):
     """[2,32,32,21] score maps whose peak has a neighbour 1 ulp below it (an EARLIER interpolated position of the x8
     up-sampled map can then round up to the peak value) or an exact earlier tie."""

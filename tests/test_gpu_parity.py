@@ -1114,6 +1114,40 @@ def test_conv7x7_as_four_4x4_blocks_f4x4_vs_oracle(gpu_engine, case):
     assert y.shape == r.shape and e7 < 1e-4 and e7 < 3 * e9 + 2e-5
 
 
+@pytest.mark.parametrize("case", [(1, 32, 32, 128, 128, 0), (1, 32, 32, 160, 128, 0), (2, 32, 32, 160, 128, 3), (1, 30, 41, 149, 128, 0), (4, 32, 32, 128, 128, 4),
+                                  (1, 9, 9, 32, 64, 2)], ids=lambda c: "B%d_%dx%d_%d-%d_ks%d" % c)
+def test_conv7x7_f4x4_channel_split_vs_oracle(gpu_engine, case):
+    """conv_wino7.hip's SPLITK form (round 5): launches that do not fill the chip -- a B = 1 PoseNet2D 7x7 layer is 8 work items on 256 CUs --
+    split the 16-channel chunks over workgroups (raw 4x4 sums into [ksplit][B*Ho*Wo][Cout]) and add the slices in conv_splitk_reduce
+    (+ bias, leaky-ReLU).  PoseNet2D's own B = 1 layers (128 and the 160-channel concat buffer: 8 and 10 chunks -> automatic split),
+    forced uneven splits, the first stage's 149 real channels on a ragged map, one tiny tile block.  Against the float64 oracle and the
+    unsplit launch; deterministic; the counter proves the split form ran."""
+    B, H, W, Cin, Cout, ks = case
+    rng = np.random.default_rng(sum(case) + 79)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    gpu_engine.set_option('wino7', '1')
+    try:
+        gpu_engine.set_option('wino_splitk', '0')
+        y1 = gpu_engine.conv2d(x, w, b, 1, True, False)
+        gpu_engine.set_option('wino_splitk', '1')
+        gpu_engine.set_option('wino7_ksplit', str(ks) if ks else 'auto')
+        n0 = gpu_engine.counter('conv_wino7_split_launches')
+        y = gpu_engine.conv2d(x, w, b, 1, True, False)
+        assert gpu_engine.counter('conv_wino7_split_launches') == n0 + 1
+        assert np.array_equal(y, gpu_engine.conv2d(x, w, b, 1, True, False)), "not deterministic"
+    finally:
+        gpu_engine.set_option('wino7', 'auto')
+        gpu_engine.set_option('wino7_ksplit', 'auto')
+        gpu_engine.set_option('wino_splitk', '1')
+    e, e1 = float(np.abs(y - r).max()), float(np.abs(y1 - r).max())
+    print("7x7 F(4x4,4x4) channel split %s: %.2e from the float64 oracle, unsplit %.2e" % (case, e, e1))
+    assert y.shape == r.shape and e < 1e-4 and e < 3 * e1 + 2e-5
+    assert float(np.abs(y - y1).max()) < 1e-4
+
+
 def test_1x1_head_pairs_as_one_launch_vs_two(gpu_engine, synth_weights):
     """conv_pw2.hip (round 5): conv6_1 + conv6_2 of HandSegNet and conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7 of PoseNet2D
     (nets/ColorHandPose3DNetwork.py:160-161,202-203,213-214) as ONE launch each, the 512- / 128-channel intermediate in LDS.  B = 24 at

@@ -459,6 +459,34 @@ def test_posenet_parity_config_c2(net, synth_weights):
         assert np.abs(a - b).max() < TOL_HEATMAP / 10
 
 
+def test_lifting_towers_on_two_streams_equal_serial(gpu_engine, synth_weights):
+    """Unfused lifting stage (batches above 4), option "lift_overlap" (round 5): ViewpointNet on the child context's stream beside PosePrior
+    (nets/ColorHandPose3DNetwork.py:231-235 -- the towers share only the pooled score map and the hand side).  Same kernels, so the
+    results are bit-identical to the one-stream run, call after call (a missing fork / join dependency would show as a difference or as
+    garbage in the rotation), growing and shrinking batches (the side tower's buffers follow), and within tolerance of the float64 oracle;
+    the counter proves the two-stream form ran."""
+    gpu_engine.load_weight_dict(synth_weights)
+    rng = np.random.default_rng(81)
+    for B in (8, 32, 6):
+        sm = np.maximum(rng.standard_normal((B, 32, 32, 21)).astype(np.float32), 0) * 0.3
+        hs = synth.hand_sides(B)
+        gpu_engine.set_option('lift_overlap', '0')
+        try:
+            n0 = gpu_engine.counter('lift_overlap_calls')
+            ref = gpu_engine.pose3d(sm, hs)
+            assert gpu_engine.counter('lift_overlap_calls') == n0
+        finally:
+            gpu_engine.set_option('lift_overlap', '1')
+        for it in range(6):
+            n0 = gpu_engine.counter('lift_overlap_calls')
+            out = gpu_engine.pose3d(sm, hs)
+            assert gpu_engine.counter('lift_overlap_calls') == n0 + 1
+            for a, b in zip(out, ref):
+                assert np.array_equal(a, b), (B, it)
+        rrel, rcan, rR = N.pose3d(synth_weights, sm[:2], hs[:2], acc=np.float64)
+        assert np.abs(out[0][:2] - rrel).max() < TOL_KP3D and np.abs(out[2][:2] - rR).max() < TOL_KP3D
+
+
 def test_pose3d_and_poseprior_variants(gpu_engine, synth_weights):
     from hand3d_amd import PosePriorNetwork
     rng = np.random.default_rng(8)

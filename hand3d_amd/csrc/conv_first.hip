@@ -35,7 +35,7 @@ constexpr int FK = 14;                      // k-steps (K = 28 >= 27)
 constexpr int FT_PITCH_H = 72;              // halves per pixel row of the F16 transpose slab (64 + 8: 144 B)
 template <bool F16>
 HP3D_KERNEL(256)
-void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
+void conv_first_kernel(const ConvParams p, int tq, int trem) {
     HP3D_DYN_SMEM(slab_all);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = HP3D_READFIRSTLANE(tid >> 6);
@@ -73,20 +73,27 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         }
     }
 
-    const int strips = (p.tiles_x + tiles_per_wg - 1) / tiles_per_wg;
-    int sp = blockIdx.x;
-    const int strip = sp % strips; sp /= strips;
-    const int ty = sp % p.tiles_y;
-    const int b = sp / p.tiles_y;
-    const int tx0 = strip * tiles_per_wg, tx1 = min(p.tiles_x, tx0 + tiles_per_wg);
+    // this workgroup's run of tiles in the launch's linear order (image, tile row, tile): the first `trem` workgroups walk tq + 1, the others tq
+    const int wg = blockIdx.x;
+    const int t0 = wg * tq + min(wg, trem), ntile = tq + (wg < trem ? 1 : 0);
+    int tx = t0 % p.tiles_x, ty, b;
+    {
+        const int row = t0 / p.tiles_x;
+        ty = row % p.tiles_y;
+        b = row / p.tiles_y;
+    }
+    int ntx = tx, nty = ty, nb = b;             // the tile whose operands are gathered next
+    auto advance = [&](int& x, int& yy, int& bb) {
+        if (++x == p.tiles_x) { x = 0; if (++yy == p.tiles_y) { yy = 0; ++bb; } }
+    };
 
     const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in, (unsigned)p.B * (unsigned)(p.H * p.W) * 12u);
     const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC(p.out, (unsigned)p.B * (unsigned)(p.H * p.W) * (unsigned)p.out_cs * (F16 ? 2u : 4u));
     constexpr int OOR = (int)0x80000000;
 
     // image operand of lane (pixel m of this wave's 2 x 16 row block, k-half kh), k-step kk: image[y+r-1][x+s-1][c]
-    const int y = ty * FT_TH + 2 * wave + (m >> 4);
-    auto gather = [&](int tx, float (&a)[NK]) {
+    auto gather = [&](int b, int ty, int tx, float (&a)[NK]) {
+        const int y = ty * FT_TH + 2 * wave + (m >> 4);
         const int x = tx * FT_TW + (m & 15);
 #pragma unroll
         for (int q = 0; q < NK; ++q) {
@@ -100,9 +107,9 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         else if (kh) a[FK - 1] = 1.0f;                    // k = 27: multiplies the bias row
     };
     float a_cur[NK], a_nxt[NK];
-    gather(tx0, a_cur);
-    for (int tx = tx0; tx < tx1; ++tx) {
-        if (tx + 1 < tx1) gather(tx + 1, a_nxt);
+    gather(nb, nty, ntx, a_cur);
+    for (int it = 0; it < ntile; ++it) {
+        if (it + 1 < ntile) { advance(ntx, nty, nb); gather(nb, nty, ntx, a_nxt); }
         f32x16 acc0, acc1;
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (F16) {
@@ -167,6 +174,7 @@ void conv_first_kernel(const ConvParams p, int tiles_per_wg) {
         }
 #pragma unroll
         for (int q = 0; q < NK; ++q) a_cur[q] = a_nxt[q];
+        advance(tx, ty, b);
     }
 }
 
@@ -178,7 +186,21 @@ int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int 
     return (long)H * W * out_cs * (f16 ? 2 : 4) < (1L << 31);      // one image inside 32-bit offsets (the launcher chunks the batch)
 }
 
-int conv_first_launch(const ConvParams& pin, hipStream_t s) {
+// resident workgroups of the kernel over the chip (3 per CU at 125 + 32 registers; asked, not assumed)
+static int conv_first_slots(bool f16) {
+    static int per_cu[2] = {0, 0};
+    if (!per_cu[f16]) {
+        int n = 0;
+#ifndef HP3D_EMU
+        const void* k = f16 ? (const void*)conv_first_kernel<true> : (const void*)conv_first_kernel<false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, 256, f16 ? 4 * 32 * FT_PITCH_H * 2 : 0) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+#endif
+        per_cu[f16] = n >= 1 ? n : 3;
+    }
+    return per_cu[f16] * hp3d_num_cus();
+}
+
+int conv_first_launch(const ConvParams& pin, hipStream_t s, int balanced) {
     ConvParams p = pin;
     p.tiles_x = (p.W + FT_TW - 1) / FT_TW;
     p.tiles_y = (p.H + FT_TH - 1) / FT_TH;
@@ -190,15 +212,18 @@ int conv_first_launch(const ConvParams& pin, hipStream_t s) {
         p.B = std::min(maxb, pin.B - b0);
         p.in = pin.in + (size_t)b0 * p.H * p.W * 3;
         p.out = (float*)((char*)pin.out + (size_t)b0 * per_img);
-        // a workgroup walks a strip of tiles of one tile row: long enough to amortise the filter load and the first gather,
-        // short enough to leave >= ~4 workgroups per CU
-        int per = p.tiles_x;
-        while (per > 4 && (long)p.B * p.tiles_y * ((p.tiles_x + per - 1) / per) < 4 * hp3d_num_cus()) per = (per + 1) / 2;
-        const int strips = (p.tiles_x + per - 1) / per;
+        // A workgroup walks a run of consecutive tiles (tile rows continue into the next row / image), every run within one tile of the same
+        // length, one workgroup per resident slot: the launch is ONE balanced round.  (Rounds 2-4 walked whole tile rows: 1280 workgroups of
+        // 20 tiles on 768 slots at 320x320, B = 32 -- 1.67 rounds; round 5.)  Small launches: runs of at least 4 tiles (filter load + first gather).
+        const long total = (long)p.B * p.tiles_y * p.tiles_x;
+        long nwg = (long)conv_first_slots(p.f16 != 0);
+        if (!balanced) nwg = (long)p.B * p.tiles_y;            // (option "first_walk" = "rows": the previous decomposition, for A/B timing)
+        nwg = std::max<long>(1, std::min(nwg, total / 4));
+        const int tq = (int)(total / nwg), trem = (int)(total % nwg);
         if (p.f16)      // half-precision output [B,H,W,out_cs halves]
-            HP3D_LAUNCH(conv_first_kernel<true>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 4 * 32 * FT_PITCH_H * 2, s, p, per);
+            HP3D_LAUNCH(conv_first_kernel<true>, dim3((unsigned)nwg), dim3(256), 4 * 32 * FT_PITCH_H * 2, s, p, tq, trem);
         else
-            HP3D_LAUNCH(conv_first_kernel<false>, dim3((unsigned)(p.B * p.tiles_y * strips)), dim3(256), 0, s, p, per);
+            HP3D_LAUNCH(conv_first_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p, tq, trem);
     }
     return 0;
 }

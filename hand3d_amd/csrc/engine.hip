@@ -271,6 +271,8 @@ struct hp3d_ctx {
     struct GraphEntry { hipGraphExec_t exec = nullptr; long epoch = -1; int calls = 0; };
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
+    long conv_first_launches = 0;
+    int first_balanced = 1;    // option "first_walk": conv_first.hip's workgroups walk balanced runs of tiles ("balanced") | whole tile rows ("rows": rounds 2-4)
     int use_first = 1;         // conv1_1 on its own kernel (conv_first.hip); conv_impl=direct keeps it on the general one
     int nstreams = -1;         // whole-path calls: halves of the batch on two HIP streams (option "streams"; -1 auto)
     hp3d_ctx* kid = nullptr;   // the second stream's context: own stream + arena, SHARES this context's weight blob
@@ -734,7 +736,8 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
         p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = f16; p.out_f32 = 0; p.nsub = 1;
         ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
-        conv_first_launch(p, ctx->stream);
+        conv_first_launch(p, ctx->stream, ctx->first_balanced);
+        ++ctx->conv_first_launches;
     } else if (f16 && ctx->use_h16 && !ctx->conv_naive &&
                ((l.mode == 0 && l.k == 3) || (ctx->h16_k7k1 && ((l.k == 7 && (l.mode == 0 || l.mode == 2)) || (l.k == 1 && l.mode == 0)))) &&
                conv_h16_eligible(ctx->use_h16, l.k, l.stride, l.cin_pad16 / 2, l.cout_pad, Ho, Wo, B, out_f32, out_cs) &&
@@ -1312,7 +1315,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1685,6 +1688,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "first_walk" && (v == "balanced" || v == "rows")) { ctx->first_balanced = v == "balanced"; return 0; }
     if (k == "lift_overlap" && (v == "0" || v == "1")) { ctx->lift_overlap = v == "1"; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino4" && (v == "0" || v == "1" || v == "pose" || v == "auto" || v == "all")) {
@@ -2161,6 +2165,27 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         pad_channels_launch(d_x, B * H * W, Cin, d_xp, l.cin_pad, ctx->stream);
     }
     float* d_out = S.alloc<float>((size_t)B * Hs * Ws * Cout); NN(ctx, d_out);
+    if (k == 3 && Cin == 3 && Cout == 64 && !pool && ctx->use_first && !ctx->conv_naive && ctx->use_wino != 2 &&
+        conv_first_eligible(k, stride, Cin, Cout, B, H, W, Cout, 0)) {
+        // the conv1_1 shape (nets/ColorHandPose3DNetwork.py:144,183) runs on the networks' own first-layer kernel (conv_first.hip)
+        ConvL l1 = l;
+        l1.mode = 1; l1.ek = 1; l1.cin_pad = 32; l1.cout_pad = 64;
+        l1.w_off = 0; l1.b_off = (size_t)32 * 64;
+        std::vector<float> pk1(l1.b_off + 64);
+        pack_conv(l1, w_hwio, bias, pk1.data());
+        float* d_pk = S.upload(pk1.data(), pk1.size()); NN(ctx, d_pk);
+        ConvParams p;
+        p.in = d_x; p.wpk = d_pk; p.bias = d_pk + l1.b_off; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = 3; p.in_cs = 3; p.Cout = 64; p.out_cs = 64; p.cout_store = 64;
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = act; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 1;
+        conv_first_launch(p, ctx->stream, ctx->first_balanced);
+        ++ctx->conv_first_launches;
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
+        return finish_op(ctx);
+    }
     int op_ks7 = 1;
     if (ctx->use_wino && ctx->use_wino7 == 1 && !ctx->conv_naive && k == 7 && !pool && Cout % 64 == 0 &&
         conv_wino7_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, nullptr, ctx->wino_splitk ? &op_ks7 : nullptr)) {
@@ -2423,6 +2448,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "conv_first_launches") { *value = ctx->conv_first_launches + (ctx->kid ? ctx->kid->conv_first_launches : 0); return 0; }
     if (k == "lift_overlap_calls") { *value = ctx->lift_overlap_calls; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }
     if (k == "conv_wino4_tail_launches") { *value = ctx->conv_wino4_tail_launches + (ctx->kid ? ctx->kid->conv_wino4_tail_launches : 0); return 0; }

@@ -300,7 +300,7 @@ int conv_h16_launch(const ConvParams& p, int pool, hipStream_t s);
 // conv1_1 (3 -> 64) computed per patch inside conv1_2 (64 -> 64, pooled): p.in = image, p.wpk1 / p.bias1 = conv1_1
 int conv_h16_fused12_launch(const ConvParams& p, hipStream_t s);
 int conv_first_eligible(int k, int stride, int Cin, int Cout, int B, int H, int W, int out_cs, int f16);
-int conv_first_launch(const ConvParams& p, hipStream_t s);
+int conv_first_launch(const ConvParams& p, hipStream_t s, int balanced = 1);
 int conv_wino_eligible(int mode, int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs,
                        int pool, int* ksplit);
 size_t wino_packed_floats(int k, int cin_pad, int cout_pad);

@@ -116,6 +116,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
  *                            MI355X (the second-stream child context grows its own), added in slice order by a small
  *                            reduce launch (deterministic; the summation order differs from the unsplit item: float32 rounding);
+ *          "first_walk"   = "balanced" (default) | "rows": conv1_1's kernel (conv_first.hip) gives every resident workgroup one run of
+ *                            consecutive 8 x 16 tiles, all runs within a tile of the same length | a whole tile row per workgroup (rounds 2-4;
+ *                            kept for A/B timing).  Bit-identical results;
  *          "lift_overlap" = "1" (default) | "0": the unfused lifting stage (batches above 4) runs ViewpointNet on a second stream beside
  *                            PosePrior (the towers share only their input, ColorHandPose3DNetwork.py:231-235; 12 + 12 short dependent launches)
  *                            | one after the other.  Same kernels, same results bit for bit;
@@ -279,6 +282,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
  * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4"),
  * "conv_wino4_tail_launches" = those of them whose last round ran as channel slices (option "wino4_tail");
  * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7"), "conv_wino7_split_launches" = those of them in the channel-split form; "conv_pw2_launches" = 1x1 layer pairs that ran as one launch (option "pw2");
+ * "conv_first_launches" = conv1_1-shaped layers (3x3, 3 -> 64) that ran on conv_first.hip;
  * "lift_overlap_calls" = lifting stages that ran their two towers on two streams (option "lift_overlap");
  * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself
  * reports them (ncclCommCount), 0 without one -- bench.py prints it so that a multi-GPU line proves its own world size. */

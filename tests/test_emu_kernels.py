@@ -427,6 +427,30 @@ def test_winograd_f4x4_4x4_channel_split_on_interpreter(emu_engine, case):
     assert np.abs(y - y1).max() < 1e-4 and not np.array_equal(y, y1)
 
 
+@pytest.mark.parametrize("case", [(3, 24, 40), (1, 16, 16), (2, 19, 37), (7, 8, 16), (1, 40, 100)], ids=lambda c: "B%d_%dx%d" % c)
+def test_first_layer_kernel_balanced_tile_runs_on_interpreter(emu_engine, case):
+    """conv_first.hip (conv1_1: 3x3, 3 -> 64, nets/ColorHandPose3DNetwork.py:144,183): a workgroup walks a RUN of consecutive 8 x 16 tiles in
+    (image, tile row, tile) order, all runs within one tile of the same length, one workgroup per resident slot (round 5; rounds 2-4 walked
+    whole tile rows).  Runs that continue into the next tile row and the next image, run lengths that differ by one, ragged right / bottom
+    tiles, fewer tiles than slots; bit-identical to the row walk (the same arithmetic per pixel), and against the float64 oracle."""
+    B, H, W = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) / np.sqrt(27)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    n0 = emu_engine.counter('conv_first_launches')
+    y = emu_engine.conv2d(x, w, b, 1, True, False)
+    assert emu_engine.counter('conv_first_launches') == n0 + 1
+    emu_engine.set_option('first_walk', 'rows')
+    try:
+        y_rows = emu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        emu_engine.set_option('first_walk', 'balanced')
+    assert y.shape == r.shape and np.abs(y - r).max() < 1e-5
+    assert np.array_equal(y, y_rows)
+
+
 def _near_tie_scoremaps(trial, rng):
     """[2,32,32,21] score maps whose peak has a neighbour 1 ulp below it (an EARLIER interpolated position of the x8
     up-sampled map can then round up to the peak value) or an exact earlier tie."""

@@ -459,6 +459,30 @@ def test_posenet_parity_config_c2(net, synth_weights):
         assert np.abs(a - b).max() < TOL_HEATMAP / 10
 
 
+@pytest.mark.parametrize("case", [(32, 320, 320), (32, 256, 256), (3, 240, 320), (1, 37, 53), (5, 200, 264)], ids=lambda c: "B%d_%dx%d" % c)
+def test_first_layer_kernel_balanced_tile_runs(gpu_engine, case):
+    """conv_first.hip (conv1_1, nets/ColorHandPose3DNetwork.py:144,183), round 5: workgroups walk balanced runs of consecutive tiles (one
+    workgroup per resident slot) instead of whole tile rows.  The bench shapes (25 600 and 16 384 tiles on 768 slots: runs of 33 / 34 and
+    21 / 22 tiles that cross tile rows and images), C1's, ragged small ones.  Bit-identical to the row walk; float64 oracle on a sample."""
+    B, H, W = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) / np.sqrt(27)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    n0 = gpu_engine.counter('conv_first_launches')
+    y = gpu_engine.conv2d(x, w, b, 1, True, False)
+    assert gpu_engine.counter('conv_first_launches') == n0 + 1
+    gpu_engine.set_option('first_walk', 'rows')
+    try:
+        y_rows = gpu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        gpu_engine.set_option('first_walk', 'balanced')
+    assert np.array_equal(y, y_rows)
+    for i in sorted({0, B // 2, B - 1}):
+        r = T.leaky_relu(T.bias_add(T.conv2d_same(x[i:i + 1], w, 1, acc=np.float64), b))
+        assert np.abs(y[i:i + 1] - r).max() < 1e-5
+
+
 def test_lifting_towers_on_two_streams_equal_serial(gpu_engine, synth_weights):
     """Unfused lifting stage (batches above 4), option "lift_overlap" (round 5): ViewpointNet on the child context's stream beside PosePrior
     (nets/ColorHandPose3DNetwork.py:231-235 -- the towers share only the pooled score map and the hand side).  Same kernels, so the

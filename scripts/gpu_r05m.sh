@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the float32 first block (conv1_1 -> conv1_2 + pool) in image chunks through a chunk-sized activation (option first_chunk),
 # with plain and non-temporal conv1_1 stores, against the whole-batch launches; same box.
+# (REJECTED: the options first_chunk / first_chunk_nt existed only for this visit and were removed from the tree afterwards -- profiles/r05_tuning_notes.md section 11)
 OUT=gpurun_out/${1:-r05m}
 mkdir -p $OUT
 B="python bench.py --cpu-seconds 0 --no-host-path --no-other-configs --steps 20 --warmup 5 --layers"

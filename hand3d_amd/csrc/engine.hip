@@ -272,6 +272,10 @@ struct hp3d_ctx {
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
     long conv_first_launches = 0;
+    int first_touch = -1;      // option "first_touch": stream conv1_1's input image through the memory-side cache right before the launch: -1 auto
+                               // (a cold image of 8 ... 128 MB), 0 never, 1 always
+    bool trunk_input_hot = false;   // set by run_trunk: the trunk's input was written by the kernel in front of it (crop, uint8 front end)
+    long first_touch_launches = 0;
     int first_balanced = 1;    // option "first_walk": conv_first.hip's workgroups walk balanced runs of tiles ("balanced") | whole tile rows ("rows": rounds 2-4)
     int use_first = 1;         // conv1_1 on its own kernel (conv_first.hip); conv_impl=direct keeps it on the general one
     int nstreams = -1;         // whole-path calls: halves of the batch on two HIP streams (option "streams"; -1 auto)
@@ -735,6 +739,16 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         p.Cin = 3; p.in_cs = 3; p.Cout = 64; p.out_cs = out_cs; p.cout_store = 64;
         p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
         p.act = l.relu; p.im2col = 1; p.ksplit = 1; p.partial = nullptr; p.f16 = f16; p.out_f32 = 0; p.nsub = 1;
+        // A COLD input image (the caller's device buffer, an upload: not written by the kernel in front of this one) costs this
+        // store-bound kernel a third of its rate -- its gathers run one tile ahead, an HBM miss takes longer than a tile (round 5: 3.5
+        // TB/s in the pipeline against 4.8 standalone and for PoseNet2D's freshly written crop).  Streaming the image once through the
+        // memory-side cache first (13 us for 39 MB) takes B = 32 at 320 x 320 from 0.253 to 0.175 ms (5.0 TB/s = 0.63 of the HBM spec).
+        const size_t img_bytes = (size_t)B * H * W * 12;
+        if (ctx->d_keys && (ctx->first_touch == 1 || (ctx->first_touch < 0 && !ctx->trunk_input_hot && img_bytes >= (8u << 20) && img_bytes <= (128u << 20)))) {
+            ProfScope pt(ctx, l.name, "conv_first_touch", 0.0, 0.0);
+            touch_launch(in, (size_t)B * H * W * 3, (float*)ctx->d_keys, ctx->stream);
+            ++ctx->first_touch_launches;
+        }
         ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
         conv_first_launch(p, ctx->stream, ctx->first_balanced);
         ++ctx->conv_first_launches;
@@ -849,7 +863,8 @@ int run_fused12(hp3d_ctx* ctx, const ConvL& l1, const ConvL& l2, const float* im
 // VGG-style trunk shared by HandSegNet and PoseNet2D: conv1_1 (im2col) ... through block 4's first
 // `n4` layers.  Returns the activation pointer / size after the trunk.
 int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H, int W, int n4, float** act, int* h,
-              int* w) {
+              int* w, bool input_hot) {
+    ctx->trunk_input_hot = input_hot;
     char nm[64];
     float* a = ctx->bufA;
     float* b = ctx->bufB;
@@ -879,9 +894,9 @@ int run_trunk(hp3d_ctx* ctx, const char* scope, const float* image, int B, int H
 }
 
 // HandSegNet (nets/ColorHandPose3DNetwork.py:131-168) -> d_segsmall [B,H/8,W/8,32] (channels 0,1 real)
-int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W) {
+int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W, bool image_hot = false) {
     float* a; int h, w;
-    CHK(run_trunk(ctx, "HandSegNet", image, B, H, W, 4, &a, &h, &w));
+    CHK(run_trunk(ctx, "HandSegNet", image, B, H, W, 4, &a, &h, &w, image_hot));
     float* b = (a == ctx->bufA) ? ctx->bufB : ctx->bufA;
     const int f16 = ctx->prec;
     CHK(run_conv(ctx, CL(ctx, "HandSegNet/conv5_1"), a, 512, B, h, w, b, 512, 0, nullptr, nullptr, f16));
@@ -897,9 +912,9 @@ int run_handsegnet(hp3d_ctx* ctx, const float* image, int B, int H, int W) {
 }
 
 // PoseNet2D (nets/ColorHandPose3DNetwork.py:170-219) -> d_sm[0..2] [B,h/8,w/8,32] (21 real channels)
-int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W) {
+int run_posenet(hp3d_ctx* ctx, const float* crop, int B, int H, int W, bool crop_hot = false) {
     float* a; int h, w;
-    CHK(run_trunk(ctx, "PoseNet2D", crop, B, H, W, 2, &a, &h, &w));
+    CHK(run_trunk(ctx, "PoseNet2D", crop, B, H, W, 2, &a, &h, &w, crop_hot));
     CHK(ensure_pose_bufs(ctx, B, h, w));
     const int f16 = ctx->prec;
     // concat([scoremap, encoding]) buffer: f32 [B,h,w,160] or f16 [B,h,w,192] (64-half chunks); channel 0..127 =
@@ -1163,8 +1178,8 @@ int copy_out(hp3d_ctx* ctx, float* dst, const float* src, size_t n, bool dev) {
 }
 
 // stages 2-8 of the full path on device-resident image/hand_side
-int run_detect_and_crop(hp3d_ctx* ctx, const float* d_image, int B, int H, int W, int want_mask) {
-    CHK(run_handsegnet(ctx, d_image, B, H, W));
+int run_detect_and_crop(hp3d_ctx* ctx, const float* d_image, int B, int H, int W, int want_mask, bool image_hot = false) {
+    CHK(run_handsegnet(ctx, d_image, B, H, W, image_hot));
     MaskBuffers mb{ctx->d_keys, ctx->d_det, nullptr};
     {
         ProfScope ps(ctx, "seg_upsample_softmax", "seg_upsample_softmax", 0.0, 4.0 * B * H * W * 2 + (double)B * H * W);
@@ -1223,8 +1238,8 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
         CHK(copy_in(ctx, ctx->d_hs, hand_side, (size_t)B * 2, false));
         d_img = ctx->d_image; d_hs = ctx->d_hs;
     }
-    CHK(run_detect_and_crop(ctx, d_img, B, H, W, hand_mask != nullptr));
-    CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256));
+    CHK(run_detect_and_crop(ctx, d_img, B, H, W, hand_mask != nullptr, image_u8 != nullptr));     // (the uint8 front end has just written the image)
+    CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256, true));
     CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED));
     if (kp_scoremap) {
         ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
@@ -1315,7 +1330,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->first_touch = ctx->first_touch; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1688,6 +1703,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "first_touch" && (v == "0" || v == "1" || v == "auto")) { ctx->first_touch = v == "auto" ? -1 : v == "1"; return 0; }
     if (k == "first_walk" && (v == "balanced" || v == "rows")) { ctx->first_balanced = v == "balanced"; return 0; }
     if (k == "lift_overlap" && (v == "0" || v == "1")) { ctx->lift_overlap = v == "1"; return 0; }
     if (k == "lift_fused" && (v == "0" || v == "1" || v == "auto")) { ctx->use_lift_fused = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
@@ -2028,7 +2044,7 @@ int hp3d_infer_2d_kp(hp3d_ctx* ctx, int B, int H, int W, const float* image, flo
         if (b0 > 0 && saved_prof == 1) ctx->profiling = 2;
         CHK(copy_in(ctx, ctx->d_image, image + (size_t)b0 * H * W * 3, (size_t)nb * H * W * 3, false));
         CHK(run_detect_and_crop(ctx, ctx->d_image, nb, H, W, 0));
-        CHK(run_posenet(ctx, ctx->d_crop, nb, 256, 256));
+        CHK(run_posenet(ctx, ctx->d_crop, nb, 256, 256, true));
         if (keypoints_scoremap) {
             resize_bilinear_launch(ctx->d_sm[2], nb, 32, 32, 21, 32, 256, 256, ctx->d_kpmap, ctx->stream);
             CHK(copy_out(ctx, keypoints_scoremap + (size_t)b0 * 256 * 256 * 21, ctx->d_kpmap, (size_t)nb * 256 * 256 * 21, false));
@@ -2448,6 +2464,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "first_touch_launches") { *value = ctx->first_touch_launches + (ctx->kid ? ctx->kid->first_touch_launches : 0); return 0; }
     if (k == "conv_first_launches") { *value = ctx->conv_first_launches + (ctx->kid ? ctx->kid->conv_first_launches : 0); return 0; }
     if (k == "lift_overlap_calls") { *value = ctx->lift_overlap_calls; return 0; }
     if (k == "lift_fused_launches") { *value = ctx->lift_fused_launches + (ctx->kid ? ctx->kid->lift_fused_launches : 0); return 0; }

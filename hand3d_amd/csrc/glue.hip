@@ -849,6 +849,23 @@ void crop_and_resize_launch(const float* img, int B, int H, int W, int C, const 
     HP3D_LAUNCH(crop_and_resize_kernel, dim3(grid_for((long)B * crop * crop)), dim3(256), 0, s, img, B, H, W, C,
                 center, scale, crop, out);
 }
+// Streams `n` floats through the caches and keeps nothing (the store below never executes for finite data): what it leaves behind is
+// the buffer resident in the memory-side cache for the gather loads of the kernel that follows (option "first_touch").
+HP3D_KERNEL(256)
+void touch_kernel(const float* p, long n4, float* sink) {
+    const f32x4* q = (const f32x4*)p;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = q[i];
+        acc += v[0] + v[1] + v[2] + v[3];
+    }
+    if (acc == 1.2345e-38f) *sink = acc;
+}
+void touch_launch(const float* p, size_t nfloats, float* sink, hipStream_t s) {
+    const long n4 = (long)(nfloats / 4);
+    if (n4 < 1 || ((uintptr_t)p & 15)) return;
+    HP3D_LAUNCH(touch_kernel, dim3(grid_for(n4, 256, 256 * 8)), dim3(256), 0, s, p, n4, sink);
+}
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s) {
     HP3D_LAUNCH(copy_channels_kernel, dim3(grid_for((long)npix * C)), dim3(256), 0, s, in, (long)npix, C, in_cs, out,
                 out_cs);

@@ -116,6 +116,11 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            items run as channel slices -- one piece per CU, raw sums to a scratch of 2 pieces x CUs x 128 KB = 64 MiB per context on a 256-CU
  *                            MI355X (the second-stream child context grows its own), added in slice order by a small
  *                            reduce launch (deterministic; the summation order differs from the unsplit item: float32 rounding);
+ *          "first_touch"  = "auto" (default) | "0" | "1": conv1_1's kernel is store-bound and gathers its operands one tile ahead; an input
+ *                            image that is COLD in the memory system (the caller's device buffer, an upload -- not the crop or the uint8
+ *                            front end's output, which the kernel in front has just written) costs it a third of its rate.  auto: such an
+ *                            image of 8 ... 128 MB is streamed once through the memory-side cache first (13 us for 39 MB; HandSegNet's
+ *                            conv1_1 at B = 32, 320 x 320: 0.253 -> 0.175 ms) | never | always.  Reads only: results unchanged;
  *          "first_walk"   = "balanced" (default) | "rows": conv1_1's kernel (conv_first.hip) gives every resident workgroup one run of
  *                            consecutive 8 x 16 tiles, all runs within a tile of the same length | a whole tile row per workgroup (rounds 2-4;
  *                            kept for A/B timing).  Bit-identical results;
@@ -282,6 +287,7 @@ int hp3d_get_timing(hp3d_ctx* ctx, float* ms_per_stage, int n);
  * "wino2"); "conv_wino4_launches" = float32 layers that ran on conv_wino4.hip (option "wino4"),
  * "conv_wino4_tail_launches" = those of them whose last round ran as channel slices (option "wino4_tail");
  * "conv_wino7_launches" = 7x7 layers that ran on conv_wino7.hip (option "wino7"), "conv_wino7_split_launches" = those of them in the channel-split form; "conv_pw2_launches" = 1x1 layer pairs that ran as one launch (option "pw2");
+ * "first_touch_launches" = read passes in front of conv1_1 (option "first_touch");
  * "conv_first_launches" = conv1_1-shaped layers (3x3, 3 -> 64) that ran on conv_first.hip;
  * "lift_overlap_calls" = lifting stages that ran their two towers on two streams (option "lift_overlap");
  * "lift_fused_launches" = lifting stages that ran as the one fused launch (option "lift_fused"); "comm_ranks" = ranks of the live RCCL communicator as RCCL itself

@@ -42,6 +42,10 @@ def family(name):
         return 'conv_first'
     if 'conv_h16_kernel' in name:
         return 'conv_h16'
+    if 'touch_kernel' in name:          # (the read pass in front of HandSegNet's conv1_1: a cold input image through the memory-side cache)
+        return 'conv_first_touch'
+    if 'wino4_tail_r' in name:
+        return 'wino4_tail_reduce'
     for k in ('conv_splitk_reduce', 'preprocess_u8', 'bone_rel_inv', 'fc_partial', 'fc_reduce', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
               'kp_detect', 'copy_channels', 'concat_handside', 'lift_epilogue', 'avgpool8', 'pad_channels'):
         if k in name:

@@ -483,6 +483,33 @@ def test_first_layer_kernel_balanced_tile_runs(gpu_engine, case):
         assert np.abs(y[i:i + 1] - r).max() < 1e-5
 
 
+def test_cold_input_image_is_streamed_through_the_cache_first(gpu_engine, synth_weights):
+    """Option "first_touch" (round 5): HandSegNet's conv1_1 gathers a COLD image (the caller's buffer / an upload) one tile ahead and loses a
+    third of its store rate to the misses; a read pass over the image in front of it warms the memory-side cache.  The pass runs once per
+    whole-path call for a batch whose image is 8 ... 128 MB (not for PoseNet2D's crop, which crop_and_resize has just written; not for
+    small batches), reads only -- results bit-identical to the run without it."""
+    from hand3d_amd import ColorHandPose3DNetwork
+    net = ColorHandPose3DNetwork(engine=gpu_engine)
+    net.init_from_dict(synth_weights)
+    img = synth.make_batch(5100, 16, 240, 320)          # 14.7 MB
+    hs = synth.hand_sides(16)
+    gpu_engine.set_option('first_touch', '0')
+    try:
+        n0 = gpu_engine.counter('first_touch_launches')
+        ref = net.inference(img, hs, True)
+        assert gpu_engine.counter('first_touch_launches') == n0
+    finally:
+        gpu_engine.set_option('first_touch', 'auto')
+    n0 = gpu_engine.counter('first_touch_launches')
+    out = net.inference(img, hs, True)
+    assert gpu_engine.counter('first_touch_launches') == n0 + 1
+    for a, b in zip(out, ref):
+        assert np.array_equal(a, b)
+    n0 = gpu_engine.counter('first_touch_launches')
+    net.inference(img[:2], hs[:2], True)                  # 1.8 MB: below the threshold
+    assert gpu_engine.counter('first_touch_launches') == n0
+
+
 def test_lifting_towers_on_two_streams_equal_serial(gpu_engine, synth_weights):
     """Unfused lifting stage (batches above 4), option "lift_overlap" (round 5): ViewpointNet on the child context's stream beside PosePrior
     (nets/ColorHandPose3DNetwork.py:231-235 -- the towers share only the pooled score map and the hand side).  Same kernels, so the

@@ -1105,7 +1105,9 @@ int ensure_side_tower(hp3d_ctx* k, int B) {
     return 0;
 }
 
-int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant) {
+// `beside` (may be null): work of the caller that depends on neither tower (the whole path's heat-map up-sampling and keypoint detection);
+// it runs on this context's stream behind PosePrior -- i.e. beside ViewpointNet when the towers run on two streams -- and before the epilogue.
+int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant, const std::function<int()>* beside = nullptr) {
     const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
     const bool fused = !ctx->conv_naive && (ctx->use_lift_fused == 1 || (ctx->use_lift_fused < 0 && B <= 4)) &&
                        (size_t)4 * B * 32 * 32 * 64 <= ctx->act_floats;
@@ -1134,6 +1136,7 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
             const int rc = run_viewpoint(k, sm32, hs, B, ctx->d_u);
             if (rc != 0) { set_error(ctx, k->err.c_str()); return rc; }
             CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
+            if (beside) { CHK((*beside)()); beside = nullptr; }
             ++ctx->lift_overlap_calls;
         }
 #endif
@@ -1142,6 +1145,7 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
             if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
         }
     }
+    if (beside) CHK((*beside)());
     if (variant == HP3D_VARIANT_LOCAL)     // bone_rel_trafo_inv (nets/PosePriorNetwork.py:70-75)
         bone_rel_inv_launch(ctx->d_can, B, ctx->d_coord, ctx->stream);
     else
@@ -1240,12 +1244,17 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
     }
     CHK(run_detect_and_crop(ctx, d_img, B, H, W, hand_mask != nullptr, image_u8 != nullptr));     // (the uint8 front end has just written the image)
     CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256, true));
-    CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED));
-    if (kp_scoremap) {
-        ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
-        resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, ctx->stream);
-    }
-    if (kp_crop || kp_image) CHK(run_kp_detect(ctx, B, kp_crop, kp_image, dev));
+    // (the heat-map up-sampling and the keypoint detection read PoseNet2D's last score map like the lifting towers do and depend on neither:
+    //  they run beside ViewpointNet when the towers take two streams, option "lift_overlap")
+    const std::function<int()> kp_work = [&]() -> int {
+        if (kp_scoremap) {
+            ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
+            resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, ctx->stream);
+        }
+        if (kp_crop || kp_image) CHK(run_kp_detect(ctx, B, kp_crop, kp_image, dev));
+        return 0;
+    };
+    CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED, &kp_work));
     CHK(copy_out(ctx, hand_scoremap, ctx->d_large, (size_t)B * H * W * 2, dev));
     CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, dev));
     CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, dev));

@@ -69,8 +69,8 @@ def test_reference_fixtures_full_pipeline_c1(net, gold):
 
 def test_reference_fixtures_batch8_on_the_headline_kernel(net, gold):
     """One batch of 8 at 240x320 through the reference's inference() (BASELINE config 4's per-GPU shard in small; utils/general.py:210
-    only needs B < H, W): from this batch size on the engine's default policy runs the trunk layers on conv_wino4.hip, so these
-    fixtures -- written by executing nets/ColorHandPose3DNetwork.py:61-99 -- meet the F(4x4,3x3) kernel directly, not through the
+    only needs B < H, W): from this batch size on the engine's default policy runs the 3x3 trunk layers on conv_wino4.hip (and the 7x7 layers on
+    conv_wino7.hip's channel-split form), so these fixtures -- written by executing nets/ColorHandPose3DNetwork.py:61-99 -- meet the F(4x4,3x3) kernel directly, not through the
     oracle chain.  Gates as everywhere: mask / centre / scale / arg-max keypoints exact, heat-maps 1e-3, 3-D keypoints 1e-4."""
     from hand3d_amd.utils.general import detect_keypoints, trafo_coords
     if not os.path.exists(os.path.join(GOLD, 'ref_c4_b8_inference.npz')):
@@ -82,11 +82,13 @@ def test_reference_fixtures_batch8_on_the_headline_kernel(net, gold):
     H, W = [int(v) for v in g['shape']]
     img = synth.make_batch(int(g['seed0']), 8, H, W)
     hs = g['hand_side']
-    c0 = net.engine.counter('conv_wino4_launches')
+    c0, c7 = net.engine.counter('conv_wino4_launches'), net.engine.counter('conv_wino7_split_launches')
     o = net.engine.infer_full(img, hs, want_mask=True)
-    n4 = net.engine.counter('conv_wino4_launches') - c0
-    print("conv_wino4 launches for the batch of 8:", n4)
-    assert n4 >= 20, "the F(4x4,3x3) kernel did not run: this test would not be holding it to the reference"
+    n4, n7 = net.engine.counter('conv_wino4_launches') - c0, net.engine.counter('conv_wino7_split_launches') - c7
+    print("batch of 8: %d conv_wino4 launches, %d conv_wino7 launches in the channel-split form" % (n4, n7))
+    # (round 5: the ten 7x7 layers of a batch this size run on conv_wino7.hip's channel-split form instead of conv_wino4's nine-block form --
+    #  so these fixtures hold that form to the reference as well)
+    assert n4 >= 10 and n4 + n7 >= 20, "the F(4x4,3x3) / F(4x4,4x4) kernels did not run: this test would not be holding them to the reference"
     for i in range(8):
         assert np.array_equal(np.packbits(o['mask'][i].astype(np.uint8)), g['mask_packed'][i]), "image %d: hand mask differs" % i
     assert np.array_equal(o['center'], g['center']) and np.array_equal(o['scale'], g['scale_crop'])

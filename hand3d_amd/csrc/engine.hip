@@ -272,6 +272,7 @@ struct hp3d_ctx {
     std::map<std::string, GraphEntry> graphs;    // hp3d_set_option("graph", "1"): replayed whole-call launch sequences
 #endif
     long conv_first_launches = 0;
+    int first_touch_beside = 1;     // option "first_touch_beside": the read pass on the child context's stream beside conv1_1 (1) | in front of it (0)
     int first_touch = -1;      // option "first_touch": stream conv1_1's input image through the memory-side cache right before the launch: -1 auto
                                // (a cold image of 8 ... 128 MB), 0 never, 1 always
     bool trunk_input_hot = false;   // set by run_trunk: the trunk's input was written by the kernel in front of it (crop, uint8 front end)
@@ -576,6 +577,8 @@ static int wino2_ks_probe(hp3d_ctx* ctx, const ConvL& l, int Ho, int Wo, int B, 
 // in: [B,H,W,in_cs] (engine channels start at `in`), out: [B,Ho',Wo',out_cs] channel 0 at `out`.
 // f16 = 1 (trunk nets after hp3d_finalize_weights(dtype=1)): `in` / `out` hold halves (except the raw image of
 // conv1_1 and out_f32 heads); in_cs / out_cs are then counted in ELEMENTS of the respective tensor.
+int kid_sync_state(hp3d_ctx* ctx);
+
 static int wino7_ks_override(const hp3d_ctx* ctx, int ks, int cin_pad, long out_floats) {        // option "wino7_ksplit"
     if (ctx->wino7_ksplit <= 0 || !ctx->wino_splitk) return ks;
     ks = std::min(ctx->wino7_ksplit, cin_pad / 16);
@@ -744,13 +747,31 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         // TB/s in the pipeline against 4.8 standalone and for PoseNet2D's freshly written crop).  Streaming the image once through the
         // memory-side cache first (13 us for 39 MB) takes B = 32 at 320 x 320 from 0.253 to 0.175 ms (5.0 TB/s = 0.63 of the HBM spec).
         const size_t img_bytes = (size_t)B * H * W * 12;
+        // The pass runs on the child context's stream BESIDE the convolution (it is ahead of the gathers after the first few tiles and
+        // needs 16 registers per wave next to the convolution's 3 x 160): its 13 us disappear; in this stream when there is no second one.
+        bool touch_beside = false;
         if (ctx->d_keys && (ctx->first_touch == 1 || (ctx->first_touch < 0 && !ctx->trunk_input_hot && img_bytes >= (8u << 20) && img_bytes <= (128u << 20)))) {
-            ProfScope pt(ctx, l.name, "conv_first_touch", 0.0, 0.0);
-            touch_launch(in, (size_t)B * H * W * 3, (float*)ctx->d_keys, ctx->stream);
+#ifndef HP3D_EMU
+            if (ctx->first_touch_beside && !ctx->use_graph && !ctx->shared_weights && !ctx->two_streams_live && kid_sync_state(ctx) == 0) {
+                hp3d_ctx* k = ctx->kid;
+                HIPCHK(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));          // (whatever produced the image on this stream comes first)
+                HIPCHK(ctx, hipStreamWaitEvent(k->stream, ctx->ev_fork, 0));
+                touch_launch(in, (size_t)B * H * W * 3, (float*)ctx->d_keys, k->stream);
+                HIPCHK(ctx, hipEventRecord(ctx->ev_join, k->stream));
+                touch_beside = true;
+            }
+#endif
+            if (!touch_beside) {
+                ProfScope pt(ctx, l.name, "conv_first_touch", 0.0, 0.0);
+                touch_launch(in, (size_t)B * H * W * 3, (float*)ctx->d_keys, ctx->stream);
+            }
             ++ctx->first_touch_launches;
         }
-        ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
-        conv_first_launch(p, ctx->stream, ctx->first_balanced);
+        {
+            ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
+            conv_first_launch(p, ctx->stream, ctx->first_balanced);
+        }
+        if (touch_beside) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the call's completion covers the read pass
         ++ctx->conv_first_launches;
     } else if (f16 && ctx->use_h16 && !ctx->conv_naive &&
                ((l.mode == 0 && l.k == 3) || (ctx->h16_k7k1 && ((l.k == 7 && (l.mode == 0 || l.mode == 2)) || (l.k == 1 && l.mode == 0)))) &&
@@ -1712,6 +1733,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "empty_reduce" && (v == "inf" || v == "fltmax")) { ctx->empty_fltmax = (v == "fltmax"); return 0; }
     if (k == "wino_splitk" && (v == "0" || v == "1")) { ctx->wino_splitk = v == "1"; return 0; }
     if (k == "wino4_tail" && (v == "0" || v == "1")) { ctx->w4_tail = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "first_touch_beside" && (v == "0" || v == "1")) { ctx->first_touch_beside = v == "1"; return 0; }
     if (k == "first_touch" && (v == "0" || v == "1" || v == "auto")) { ctx->first_touch = v == "auto" ? -1 : v == "1"; return 0; }
     if (k == "first_walk" && (v == "balanced" || v == "rows")) { ctx->first_balanced = v == "balanced"; return 0; }
     if (k == "lift_overlap" && (v == "0" || v == "1")) { ctx->lift_overlap = v == "1"; return 0; }

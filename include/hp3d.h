@@ -121,6 +121,7 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            front end's output, which the kernel in front has just written) costs it a third of its rate.  auto: such an
  *                            image of 8 ... 128 MB is streamed once through the memory-side cache first (13 us for 39 MB; HandSegNet's
  *                            conv1_1 at B = 32, 320 x 320: 0.253 -> 0.175 ms) | never | always.  Reads only: results unchanged;
+ *          "first_touch_beside" = "1" (default) | "0": that read pass runs on a second stream beside conv1_1 | in front of it;
  *          "first_walk"   = "balanced" (default) | "rows": conv1_1's kernel (conv_first.hip) gives every resident workgroup one run of
  *                            consecutive 8 x 16 tiles, all runs within a tile of the same length | a whole tile row per workgroup (rounds 2-4;
  *                            kept for A/B timing).  Bit-identical results;

@@ -771,7 +771,9 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
             ProfScope ps(ctx, l.name, f16 ? "conv_first_3x3_c3_f16" : "conv_first_3x3_c3", flops, bytes);
             conv_first_launch(p, ctx->stream, ctx->first_balanced);
         }
+#ifndef HP3D_EMU
         if (touch_beside) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));      // the call's completion covers the read pass
+#endif
         ++ctx->conv_first_launches;
     } else if (f16 && ctx->use_h16 && !ctx->conv_naive &&
                ((l.mode == 0 && l.k == 3) || (ctx->h16_k7k1 && ((l.k == 7 && (l.mode == 0 || l.mode == 2)) || (l.k == 1 && l.mode == 0)))) &&

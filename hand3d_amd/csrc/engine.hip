@@ -1187,7 +1187,7 @@ int need_nets(hp3d_ctx* ctx, int mask) {
 int check_img(hp3d_ctx* ctx, int B, int H, int W) {
     if (B < 1 || H < 16 || W < 16)
         HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad shape B=%d H=%d W=%d (need B>=1, H,W >=16)", B, H, W);
-    if ((size_t)3 * H * ((W + 31) / 32) * 4 > 160 * 1024 - 1024)
+    if (mask_grow_lds_bytes(H, W) > 160 * 1024 - 1024)
         HP3D_FAIL(ctx, HP3D_ERR_ARG, "image %dx%d too large for the in-LDS mask growth", H, W);
     return 0;
 }
@@ -2416,7 +2416,7 @@ int hp3d_mask_from_scoremap(hp3d_ctx* ctx, const float* scoremap, int B, int H, 
     if (!ctx) return HP3D_ERR_ARG;
     if (!scoremap || B < 1 || H < 1 || W < 1) HP3D_FAIL(ctx, HP3D_ERR_ARG, "bad arguments");
     if (!(B < H && B < W)) HP3D_FAIL(ctx, HP3D_ERR_ARG, "Scoremap must be [Batch, Width, Height]");  // general.py:210
-    if ((size_t)3 * H * ((W + 31) / 32) * 4 > 160 * 1024 - 1024) HP3D_FAIL(ctx, HP3D_ERR_ARG, "map too large");
+    if (mask_grow_lds_bytes(H, W) > 160 * 1024 - 1024) HP3D_FAIL(ctx, HP3D_ERR_ARG, "map too large");
     HIPCHK(ctx, hipSetDevice(ctx->device));
     Scratch S(ctx);
     const size_t npx = (size_t)B * H * W;

@@ -409,18 +409,20 @@ void seg_softmax_kernel(const float* large, int B, int H, int W, unsigned char* 
 // Seeded geodesic growth + bounding box (utils/general.py:247-328), one workgroup per image.
 // O_0 = {seed};  O_{j+1} = det AND dilate21x21(O_j), j < max(H,W)//10 passes, bit-packed in LDS;
 // stops early at a fix-point (exactly equivalent: the iteration is deterministic).
-// Row r of the bitmap is WW = ceil(W/32) words; pixel x is bit x%32 of word x/32.
+// Row r of the bitmap is WW = ceil(W/32) words + ONE zero guard word (pitch P = WW + 1): pixel x is bit x%32 of word x/32; the guard word is
+// the right neighbour of the row's last word and the left neighbour of the next row's first, so the horizontal pass reads its neighbours
+// without knowing its column (round 5: `w % WW` and `u / WW` per word and pass were a third of the pass's instructions).
 constexpr int MG_R = 12;          // rows per thread in the vertical pass of mask_grow
 HP3D_KERNEL(1024)
 void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, int H, int W, int empty_fltmax,
                       float* mask_out, float* center, float* crop_size, float* scale, int* seed_out) {
     HP3D_DYN_SMEM(smem_f);
+    const int WW = (W + 31) >> 5, P = WW + 1;
+    const int NWORD = H * P;                     // words of a bitmap incl. the guard column
     unsigned* detb = (unsigned*)smem_f;
-    const int WW = (W + 31) >> 5;
-    const int NWORD = H * WW;
-    unsigned* obj = detb + NWORD;
-    unsigned* tmp = obj + NWORD;
-    __shared__ int s_changed, s_rmin, s_rmax, s_cmin, s_cmax;
+    unsigned* obj = detb + NWORD + 1;            // obj[-1] and obj[NWORD] exist and stay zero (neighbours of the first / last word)
+    unsigned* tmp = obj + NWORD + 1;
+    __shared__ int s_changed[2], s_rmin, s_rmax, s_cmin, s_cmax;
 
     const int b = blockIdx.x, tid = threadIdx.x, nthr = blockDim.x;
     const unsigned char* d = det + (size_t)b * H * W;
@@ -428,10 +430,12 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
     const int sy = (int)(idx / (unsigned)W), sx = (int)(idx % (unsigned)W);
 
     for (int w = tid; w < NWORD; w += nthr) {
-        const int y = w / WW, wx = w - y * WW;
+        const int y = w / P, wx = w - y * P;
         unsigned bits = 0;
         const unsigned char* row = d + (size_t)y * W + wx * 32;
-        if (wx * 32 + 32 <= W && ((W & 7) == 0)) {          // 4 aligned 8-byte loads instead of 32 byte loads
+        if (wx == WW) {
+            // guard word
+        } else if (wx * 32 + 32 <= W && ((W & 7) == 0)) {          // 4 aligned 8-byte loads instead of 32 byte loads
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const unsigned long long v = *(const unsigned long long*)(row + q * 8);
@@ -448,20 +452,17 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
         detb[w] = bits;
         obj[w] = (y == sy && wx == (sx >> 5)) ? (1u << (sx & 31)) : 0u;
     }
-    if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_cmin = 0x7fffffff; s_cmax = -1; }
+    if (tid == 0) { s_rmin = 0x7fffffff; s_rmax = -1; s_cmin = 0x7fffffff; s_cmax = -1; s_changed[0] = s_changed[1] = 0; obj[-1] = 0u; obj[NWORD] = 0u; }
     __syncthreads();
 
+    // this thread's first unit of the vertical pass (MG_R rows of one word column), computed once; images beyond 1024 units pay the division
+    const int nseg = (H + MG_R - 1) / MG_R, nunits = nseg * WW;
+    const int u0seg = tid / WW, u0wx = tid - u0seg * WW;
     const int num_passes = max(H, W) / 10;   // max(s[1], s[2]) // (filter_size // 2)
     for (int pass = 0; pass < num_passes; ++pass) {
-        if (tid == 0) s_changed = 0;
-        // horizontal dilation, radius 10
+        // horizontal dilation, radius 10: three independent LDS reads; the guard words make the row ends (their own results are never read)
         for (int w = tid; w < NWORD; w += nthr) {
-            const int wx = w % WW;
-            // neighbours read unconditionally (clamped index) and masked afterwards: three independent LDS reads in flight
-            const unsigned lo_r = obj[w > 0 ? w - 1 : 0], mid_r = obj[w], hi_r = obj[w + 1 < NWORD ? w + 1 : w];
-            const unsigned long long lo = wx > 0 ? lo_r : 0u;
-            const unsigned long long mid = mid_r;
-            const unsigned long long hi = wx + 1 < WW ? hi_r : 0u;
+            const unsigned long long lo = obj[w - 1], mid = obj[w], hi = obj[w + 1];
             unsigned long long win = (mid << 16) | (lo >> 16) | (hi << 48);
             win = win | (win << 1) | (win >> 1);     // radius 1
             win = win | (win << 2) | (win >> 2);     // radius 3
@@ -470,22 +471,25 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
             tmp[w] = (unsigned)(win >> 16);
         }
         __syncthreads();
+        // (two "changed" flags, one barrier saved per pass: the other parity's flag is cleared HERE -- every thread has read it for the
+        //  previous pass's exit test before it arrived at the barrier above, and its next writers come after the next two barriers)
+        if (tid == 0) s_changed[(pass + 1) & 1] = 0;
         // vertical dilation, radius 10, AND det.  A thread owns MG_R consecutive rows of one word column: it reads the
         // MG_R + 20 rows it needs once and forms the 21-row ORs by doubling (2, 4, 8, 16 rows, then 16 + 4 + 1), ~10 ORs and
         // 2.7 LDS reads per output instead of 21 + 21
         int changed = 0;
-        const int nseg = (H + MG_R - 1) / MG_R;
-        for (int u = tid; u < nseg * WW; u += nthr) {
-            const int seg = u / WW, wx = u - seg * WW;
+        for (int u = tid, k = 0; u < nunits; u += nthr, ++k) {
+            int seg = u0seg, wx = u0wx;
+            if (k) { seg = u / WW; wx = u - seg * WW; }
             const int y0 = seg * MG_R;
             unsigned v[MG_R + 20];
             // all MG_R + 20 reads are issued unconditionally (rows outside the image read the unit's own first word and are
             // masked to zero afterwards): no branches, no serialised waits
-            const int base = (y0 - 10) * WW + wx;
+            const int base = (y0 - 10) * P + wx;
 #pragma unroll
             for (int i = 0; i < MG_R + 20; ++i) {
                 const bool ok = (unsigned)(y0 - 10 + i) < (unsigned)H;
-                const unsigned r = tmp[ok ? base + i * WW : wx];
+                const unsigned r = tmp[ok ? base + i * P : wx];
                 v[i] = ok ? r : 0u;
             }
             unsigned a2[MG_R + 17], a4[MG_R + 5];
@@ -505,19 +509,17 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
             for (int j = 0; j < MG_R; ++j) {
                 const int y = y0 + j;
                 if (y < H) {
-                    const int w = y * WW + wx;
+                    const int w = y * P + wx;
                     const unsigned acc = (a4[j] | a2[j + 16] | v[j + 20]) & detb[w];     // rows y-10 .. y+10
                     if (acc != obj[w]) changed = 1;
-                    // obj is only read through tmp in this phase -> safe to update in place
+                    // obj is only read through tmp in this phase -> safe to update in place (its guard words are never written)
                     obj[w] = acc;
                 }
             }
         }
-        if (changed) s_changed = 1;
+        if (changed) s_changed[pass & 1] = 1;
         __syncthreads();
-        const int any = s_changed;
-        __syncthreads();
-        if (!any) break;
+        if (!s_changed[pass & 1]) break;
     }
 
     // bounding box (calc_center_bb): "x" = row index, "y" = column index
@@ -525,7 +527,7 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
     for (int w = tid; w < NWORD; w += nthr) {
         const unsigned v = obj[w];
         if (v) {
-            const int y = w / WW, wx = w - y * WW;
+            const int y = w / P, wx = w - y * P;
             rmin = min(rmin, y); rmax = max(rmax, y);
             cmin = min(cmin, wx * 32 + (__ffs(v) - 1));
             cmax = max(cmax, wx * 32 + (31 - __clz(v)));
@@ -540,7 +542,7 @@ void mask_grow_kernel(const unsigned char* det, const unsigned long long* keys, 
         float* mo = mask_out + (size_t)b * H * W;
         for (int i = tid; i < H * W; i += nthr) {
             const int y = i / W, x = i - y * W;
-            mo[i] = (obj[y * WW + (x >> 5)] >> (x & 31)) & 1u ? 1.f : 0.f;
+            mo[i] = (obj[y * P + (x >> 5)] >> (x & 31)) & 1u ? 1.f : 0.f;
         }
     }
     if (tid == 0) {
@@ -891,10 +893,11 @@ void seg_softmax_launch(const float* scoremap_large, int B, int H, int W, const 
     HP3D_LAUNCH(seg_softmax_kernel, dim3(gx, B), dim3(256), 0, s, scoremap_large, B, H, W, mb.det, mb.fg,
                 mb.argmax_key);
 }
+// three bitmaps of H rows x (ceil(W / 32) + 1 guard) words, + the two end guards of the growing one
+size_t mask_grow_lds_bytes(int H, int W) { return ((size_t)3 * H * ((W + 31) / 32 + 1) + 2) * sizeof(unsigned); }
 void mask_grow_launch(const MaskBuffers& mb, int B, int H, int W, int empty_fltmax, float* mask_out, float* center,
                       float* crop_size, float* scale, int* seed, hipStream_t s) {
-    const int WW = (W + 31) / 32;
-    const size_t smem = (size_t)3 * H * WW * sizeof(unsigned);
+    const size_t smem = mask_grow_lds_bytes(H, W);
     static bool attr_done[64] = {};
     if (hp3d_first_use_on_device(attr_done))
         (void)hipFuncSetAttribute((const void*)mask_grow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);

@@ -375,6 +375,7 @@ void kp_detect_launch(const float* sm, int B, int h, int w, int C, int cs, int o
                       const float* center, int* kp_crop, double* kp_image, hipStream_t s);
 void argmax2d_launch(const float* x, int B, int H, int W, int C, int cs, int* out_rc, hipStream_t s);
 void copy_channels_launch(const float* in, int npix, int C, int in_cs, float* out, int out_cs, hipStream_t s);
+size_t mask_grow_lds_bytes(int H, int W);
 void touch_launch(const float* p, size_t nfloats, float* sink, hipStream_t s);
 void cvt_channels_f16_launch(const float* in, int npix, int C, int in_cs, hp3d_f16* out, int out_cs, hipStream_t s);
 void pad_channels_launch(const float* in, int npix, int C, float* out, int out_cs, hipStream_t s);

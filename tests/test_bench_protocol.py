@@ -168,3 +168,30 @@ def test_bench_refuses_more_gpus_than_devices(launched):
     assert out.returncode == 3 and out.stdout.strip() == ''
     assert 'only 2 HIP device(s)' in out.stderr and 'FAKELOG rank' not in out.stderr.replace('FAKELOG rank %s: \n' % env.get('RANK', '-'), '')
     assert time.time() - t0 < 60
+
+
+def test_bench_family_accounting_of_the_profile_rows():
+    """bench.py's roofline blocks are sums over per-launch profile rows (layer, kernel, ms, flops, bytes): the Winograd kernels with 4x4
+    output tiles form ONE family whose EXECUTED flops are the algorithmic ones times the products each form really multiplies (F(4x4,3x3)
+    36/144, a 7x7 filter as nine blocks 289/784, as four F(4x4,4x4) blocks 169/784); conv1_1's read pass (`conv_first_touch`, round 5)
+    adds its TIME to the conv_first family but is neither a launch of that kernel nor algorithmic bytes -- so the family's HBM fraction
+    cannot improve by hiding the pass."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = [('a/conv1_1', 'conv_first_touch', 0.010, 0.0, 0.0), ('a/conv1_1', 'conv_first_3x3_c3', 0.170, 1e9, 8.78e8),
+            ('b/conv1_1', 'conv_first_3x3_c3', 0.120, 1e9, 5.62e8),
+            ('a/conv3_2', 'conv_wino4_f4x4_3x3', 0.5, 144e9, 1e8), ('b/conv6_2', 'conv_wino7_f4x4_4x4_as7x7', 0.1, 78.4e9, 1e7),
+            ('b/conv6_3', 'conv_wino4_f4x4_3x3_as7x7_splitk', 0.2, 78.4e9, 1e7), ('x', 'conv_pw2_1x1_1x1', 0.05, 1e9, 1e6)]
+    fam, total = bench.families(rows)
+    assert abs(total - sum(r[2] for r in rows)) < 1e-12
+    cf = fam['conv_first_3x3_c3']
+    assert abs(cf[0] - 0.300) < 1e-12 and cf[3] == 2 and cf[2] == 8.78e8 + 5.62e8
+    w4 = fam['conv_wino4']
+    assert w4[3] == 3 and abs(w4[4] - (144e9 * 36 / 144 + 78.4e9 * 169 / 784 + 78.4e9 * 289 / 784)) < 1.0
+    roof = bench.roof_of_family(fam, 'conv_first_3x3_c3', total, 157.3)
+    assert roof['bound'] == 'hbm' and roof['launches'] == 2 and abs(roof['achieved'] - (8.78e8 + 5.62e8) / 0.300e-3 / 1e9) < 0.1
+    assert abs(roof['frac'] - roof['achieved'] / roof['peak']) < 1e-3
+    r4 = bench.roof_of_family(fam, 'conv_wino4', total, 157.3)
+    assert r4['bound'] == 'mfma' and abs(r4['achieved'] - w4[4] / 0.8e-3 / 1e12) < 0.01 and r4['achieved'] < r4['achieved_algorithmic']

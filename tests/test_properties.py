@@ -95,3 +95,54 @@ def test_fc_random_shapes(emu_engine, B, Cin, Cout, seed):
     w = (rng.standard_normal((Cin, Cout)) / np.sqrt(Cin)).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
     assert np.abs(emu_engine.fc(x, w, b, False) - T.fully_connected(x, w, b, np.float64)).max() < 1e-5
+
+
+@settings(max_examples=10, **COMMON)
+@given(H=st.integers(1, 22), W=st.integers(1, 22), Cin=st.integers(1, 100), Cout=st.sampled_from([64, 128, 192]), B=st.integers(1, 3),
+       act=st.booleans(), ks=st.integers(0, 7), seed=st.integers(0, 10 ** 6))
+def test_winograd_f4x4_4x4_random_geometry_and_channel_splits(emu_engine, H, W, Cin, Cout, B, act, ks, seed):
+    """conv_wino7.hip forced on (round 5: a 7x7 filter as four F(4x4,4x4) blocks): maps smaller than one window, ragged tile blocks, channel
+    counts that need zero padding to a 16-channel chunk, several images / items per workgroup -- unsplit, and with the chunks split over
+    workgroups (`wino7_ksplit` = 0: the automatic choice; N: forced, clamped to the number of chunks) + the deterministic reduce."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((7, 7, Cin, Cout)) / np.sqrt(49 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b)
+    if act:
+        r = T.leaky_relu(r)
+    emu_engine.set_option('wino7', '1')
+    try:
+        emu_engine.set_option('wino_splitk', '0')
+        n0 = emu_engine.counter('conv_wino7_launches')
+        y1 = emu_engine.conv2d(x, w, b, 1, act, False)
+        assert emu_engine.counter('conv_wino7_launches') == n0 + 1
+        emu_engine.set_option('wino_splitk', '1')
+        emu_engine.set_option('wino7_ksplit', str(ks) if ks else 'auto')
+        y = emu_engine.conv2d(x, w, b, 1, act, False)
+    finally:
+        emu_engine.set_option('wino7', 'auto')
+        emu_engine.set_option('wino7_ksplit', 'auto')
+        emu_engine.set_option('wino_splitk', '1')
+    assert y.shape == r.shape and np.abs(y1 - r).max() < 1e-4 and np.abs(y - r).max() < 1e-4
+
+
+@settings(max_examples=10, **COMMON)
+@given(H=st.integers(16, 60), W=st.integers(16, 70), B=st.integers(1, 4), seed=st.integers(0, 10 ** 6))
+def test_first_layer_kernel_random_geometry(emu_engine, H, W, B, seed):
+    """conv_first.hip (conv1_1's shape through the per-op entry point): balanced runs of tiles over ragged tile grids and batches; the row
+    walk of rounds 2-4 must give the same bits."""
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((B, H, W, 3)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64)) / np.sqrt(27)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    n0 = emu_engine.counter('conv_first_launches')
+    y = emu_engine.conv2d(x, w, b, 1, True, False)
+    assert emu_engine.counter('conv_first_launches') == n0 + 1
+    emu_engine.set_option('first_walk', 'rows')
+    try:
+        y_rows = emu_engine.conv2d(x, w, b, 1, True, False)
+    finally:
+        emu_engine.set_option('first_walk', 'balanced')
+    assert np.abs(y - r).max() < 1e-5 and np.array_equal(y, y_rows)

@@ -1,6 +1,6 @@
 """Builds libhp3d.so (hand-written HIP for gfx950) in-tree with hipcc.
 
-No torch, no cmake: three translation units -> one shared library with a C ABI (include/hp3d.h).
+No torch, no cmake: one translation unit per kernel family + the executor -> one shared library with a C ABI (include/hp3d.h).
 `-ffp-contract=off`: the glue kernels restate float32 op-by-op arithmetic of the reference
 (box / interpolation coordinates feed discontinuous decisions); the MFMA conv is unaffected.
 """
@@ -11,7 +11,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libhp3d.so')
-SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
+SOURCES = ['conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino4s.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip']
 HEADERS = ['hp3d_common.h', 'lift_fused.h', 'wino4_shared.h', 'wino4_diag.h', os.path.join('..', '..', 'include', 'hp3d.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result', '-Wno-unused-value']
@@ -20,6 +20,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 # (-pragma-unroll-threshold: its 36-plane step body is one straight-line block by design; past the default limit hipcc silently
 # stops unrolling and the 288 accumulators land in scratch)
 EXTRA_FLAGS = {'conv_wino4.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000'],
+               'conv_wino4s.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000'],     # (the split-operand form of the same kernel)
                'conv_wino7.hip': ['-ffp-contract=fast', '-mllvm', '-pragma-unroll-threshold=100000']}      # (F(4x4,4x4) for the 7x7 layers: the same reasons)
 
 

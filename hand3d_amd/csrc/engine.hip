@@ -56,6 +56,7 @@ struct ConvL {
     size_t ww_off = 0;     // Winograd-transformed filters U[16][cin_pad][cout_pad] (3x3/s1, cout%64==0), 0 = none
     size_t ww2_off = 0;    // the same filters in conv_wino2.hip's fragment order (two workgroups per CU), 0 = none
     size_t ww4_off = 0;    // F(4x4,3x3) filters U[36][...] in conv_wino4.hip's fragment order (trunk nets), 0 = none
+    size_t ww4s_off = 0;   // the F(4x4,3x3) filters split into three bfloat16 pieces in conv_wino4s.hip's fragment order (3x3 trunk layers with Cin >= 128), 0 = none
     size_t ww7_off = 0;    // 7x7 layers: F(4x4,4x4) filters of the four 4x4-tap blocks in conv_wino7.hip's order [chunk][169][Cout/16][q][n][e], 0 = none
     size_t raw_off = 0;    // lifting nets only: [Cout/64][cin4][tap][64] for lift_fused.hip (one contiguous weight stream per wave), 0 = none
     int cin4 = 0;
@@ -102,6 +103,11 @@ struct Tables {
                 if (k == 7) {
                     l.ww7_off = blob_floats;
                     blob_floats += wino7_packed_floats(l.cin_pad, l.cout_pad);
+                }
+                if (k == 3 && l.mode == 0 && l.cin_pad >= 128 && l.cin_pad % 16 == 0) {
+                    blob_floats = (blob_floats + 3) / 4 * 4;
+                    l.ww4s_off = blob_floats;
+                    blob_floats += (wino4s_packed_bytes(l.cin_pad, l.cout_pad) + 15) / 16 * 4;
                 }
             }
         }
@@ -300,6 +306,10 @@ struct hp3d_ctx {
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
+    int use_wino4s = 0;        // conv_wino4s.hip (F(4x4,3x3) on the bf16 matrix pipe, split operands), option "wino4_split": 0 never, -1 "auto" (the filled
+                               // 3x3 launches with Cin >= 128 that conv_wino4.hip would take), 1 wherever eligible (tests)
+    long conv_wino4s_launches = 0;
+    long conv_wino4s_tail_launches = 0;
     int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
     int use_pw2 = 1;           // conv_pw2.hip: the 1x1 head pairs (conv6_1 + conv6_2, conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7) as one launch each
                                // (option "pw2": 0 never, 1 when the launch has a workgroup per CU, 2 = "force": whenever the shapes allow, tests)
@@ -656,6 +666,40 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
         (ctx->use_wino4 == 1 ||
          (ctx->use_wino4 < 0 && wino4_auto(ctx->use_wino4, l.net == NET_POSE, l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, wino4_ks, old_nt, wino_ks,
                                            wino2_ks_probe(ctx, l, Ho, Wo, B, in_cs, out_cs, pool), ctx->two_streams_live)));
+    // round 6: the filled 3x3 launches with Cin >= 128 on the bf16 matrix pipe with split operands (conv_wino4s.hip), option "wino4_split"
+    int filled4s = 0;
+    const bool take4s = ctx->use_wino && ctx->use_wino4s && !f16 && l.ww4s_off && !ctx->conv_naive && l.k == 3 &&
+        conv_wino4s_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, &filled4s) &&
+        (ctx->use_wino4s == 1 || (take4 && wino4_ks <= 1 && filled4s));
+    if (take4s) {
+        ConvParams p;
+        p.in = in; p.wpk = ctx->blob + l.ww4s_off; p.bias = ctx->blob + l.b_off; p.out = out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = in_cs; p.Cout = l.cout_pad; p.out_cs = out_cs;
+        p.cout_store = std::min(l.cout_pad, out_cs);
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = l.relu; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 1;
+        if (ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+            const size_t need = conv_wino4s_tail_floats();
+            if (need > ctx->col_floats) {
+                HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+                CHK(dev_realloc(ctx, &ctx->col, need));
+                ctx->col_floats = need;
+            }
+            p.partial = ctx->col; p.partial_cap = ctx->col_floats;
+        }
+        {
+            ProfScope ps(ctx, l.name, pool ? "conv_wino4s_f4x4_3x3_bf16x3_pool" : "conv_wino4s_f4x4_3x3_bf16x3", flops, bytes);
+            const int lr = conv_wino4s_launch(p, pool, ctx->stream);
+            if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,3x3), split operands): launch refused");
+            if (lr == 1) ++ctx->conv_wino4s_tail_launches;
+        }
+        ++ctx->conv_wino4s_launches;
+        HIPCHK(ctx, hipGetLastError());
+        if (Ho_out) *Ho_out = pool ? Ho / 2 : Ho;
+        if (Wo_out) *Wo_out = pool ? Wo / 2 : Wo;
+        return 0;
+    }
     const bool take2 = !take4 && ctx->use_wino && ctx->use_wino2 && !f16 && l.ww2_off && !ctx->conv_naive &&
         conv_wino2_eligible(l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool, ctx->wino_splitk ? &wino2_ks : nullptr) &&
         (ctx->use_wino2 == 1 || wino2_auto(l.k, l.cin_pad, l.cout_pad, Ho, Wo, B, old_nt, wino_ks, wino2_ks, ctx->two_streams_live));
@@ -1376,7 +1420,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->first_touch = ctx->first_touch; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->first_touch = ctx->first_touch; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->use_wino4s = ctx->use_wino4s; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1758,6 +1802,7 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
         ctx->use_wino4 = v == "auto" ? wino4_default() : v == "all" ? -2 : v == "1" ? 1 : v == "pose" ? -1 : 0;
         return 0;
     }
+    if (k == "wino4_split" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino4s = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "pw2" && (v == "0" || v == "1" || v == "force")) { ctx->use_pw2 = v == "0" ? 0 : v == "1" ? 1 : 2; return 0; }
     if (k == "wino7_ksplit") { ctx->wino7_ksplit = v == "auto" ? 0 : std::max(0, atoi(v.c_str())); return 0; }
     if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
@@ -1893,6 +1938,7 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
                 wino2_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww2_off);
                 if (l.ww4_off) wino4_pack_weights(w->data.data(), l.k, l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww4_off);
                 if (l.ww7_off) wino7_pack_weights(w->data.data(), l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww7_off);
+                if (l.ww4s_off) wino4s_pack_weights(w->data.data(), l.cin, l.cout, l.cin_pad, l.cout_pad, cmap.data(), hp + l.ww4s_off);
             }
         });
     }
@@ -2278,6 +2324,32 @@ int hp3d_conv2d(hp3d_ctx* ctx, const float* x, int B, int H, int W, int Cin, con
         HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
         return finish_op(ctx);
     }
+    if (ctx->use_wino && ctx->use_wino4s == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
+        conv_wino4s_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, nullptr)) {
+        // option "wino4_split" = "1": the F(4x4,3x3) kernel with split bfloat16 operands (conv_wino4s.hip)
+        const size_t wn = (wino4s_packed_bytes(l.cin_pad, l.cout_pad) + 15) / 16 * 4;
+        std::vector<float> pw(wn + l.cout_pad, 0.f);
+        wino4s_pack_weights(w_hwio, Cin, Cout, l.cin_pad, l.cout_pad, nullptr, pw.data());
+        for (int co = 0; co < Cout; ++co) pw[wn + co] = bias[co];
+        float* d_pk = S.upload(pw.data(), pw.size()); NN(ctx, d_pk);
+        ConvParams p;
+        p.in = d_xp; p.wpk = d_pk; p.bias = d_pk + wn; p.out = d_out;
+        p.B = B; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo;
+        p.Cin = l.cin_pad; p.in_cs = l.cin_pad; p.Cout = l.cout_pad; p.out_cs = Cout; p.cout_store = Cout;
+        p.pad_t = pt; p.pad_l = pl; p.tiles_x = 0; p.tiles_y = 0;
+        p.act = act; p.im2col = 0; p.ksplit = 1; p.partial = nullptr; p.f16 = 0; p.out_f32 = 0; p.nsub = 1;
+        if (ctx->w4_tail && conv_wino4_tail_plan(l.cin_pad, l.cout_pad, Ho, Wo, B, nullptr) > 0) {
+            p.partial = S.alloc<float>(conv_wino4s_tail_floats()); NN(ctx, p.partial);
+            p.partial_cap = conv_wino4s_tail_floats();
+        }
+        const int lr = conv_wino4s_launch(p, pool, ctx->stream);
+        if (lr < 0) HP3D_FAIL(ctx, HP3D_ERR_ARG, "winograd conv (F(4x4,3x3), split operands): launch refused");
+        if (lr == 1) ++ctx->conv_wino4s_tail_launches;
+        ++ctx->conv_wino4s_launches;
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)B * Hs * Ws * Cout, hipMemcpyDeviceToHost, ctx->stream));
+        return finish_op(ctx);
+    }
     int op_ks = 1, op_ks2 = 1;
     const bool op4 = ctx->use_wino && ctx->use_wino4 == 1 && !ctx->conv_naive && Cout % 64 == 0 &&
         conv_wino4_eligible(k, stride, l.cin_pad, l.cout_pad, Ho, Wo, B, l.cin_pad, Cout, pool, ctx->wino_splitk ? &op_ks2 : nullptr);
@@ -2519,6 +2591,8 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "conv_pw2_launches") { *value = ctx->conv_pw2_launches + (ctx->kid ? ctx->kid->conv_pw2_launches : 0); return 0; }
     if (k == "conv_wino7_split_launches") { *value = ctx->conv_wino7_split_launches + (ctx->kid ? ctx->kid->conv_wino7_split_launches : 0); return 0; }
     if (k == "conv_wino7_launches") { *value = ctx->conv_wino7_launches + (ctx->kid ? ctx->kid->conv_wino7_launches : 0); return 0; }
+    if (k == "conv_wino4s_launches") { *value = ctx->conv_wino4s_launches + (ctx->kid ? ctx->kid->conv_wino4s_launches : 0); return 0; }
+    if (k == "conv_wino4s_tail_launches") { *value = ctx->conv_wino4s_tail_launches + (ctx->kid ? ctx->kid->conv_wino4s_tail_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }
     if (k == "conv_wino2_launches") { *value = ctx->conv_wino2_launches + (ctx->kid ? ctx->kid->conv_wino2_launches : 0); return 0; }
     if (k == "comm_ranks") { *value = comm_ranks(ctx); return 0; }

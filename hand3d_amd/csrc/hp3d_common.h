@@ -17,6 +17,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((vector_size(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two float32 -> two bfloat16 (round to nearest even), `lo` in bits 0..15
+static __device__ __forceinline__ unsigned hp3d_cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 // wave-level rendezvous for data exchanged through LDS inside ONE wave
 #define HP3D_WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 #define HP3D_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) float name[]
@@ -105,6 +112,20 @@ typedef _Float16 f16x4 __attribute__((vector_size(8)));
                  "v_mfma_f32_16x16x4_f32 %1, %3, %4, 0"                                                              \
                  : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
                  : "v"(a0e), "v"(a1e), "v"(be))
+// conv_wino4s.hip: v_mfma_f32_16x16x32_bf16 on both tile halves with one B fragment (A, B: 4 registers = 8 bfloat16, lane l carries
+// k = 8 (l >> 4) .. + 7; D as the f32 16x16x4 form); accumulators pinned by REG like conv_wino4.hip's
+#define HP3D_MFMA16B_PAIR(REG, acc0, acc1, a0, a1, b)                                                               \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, %0\n\t"                                                     \
+                 "v_mfma_f32_16x16x32_bf16 %1, %3, %4, %1"                                                           \
+                 : "+" REG(acc0), "+" REG(acc1)                                                                     \
+                 : "v"(a0), "v"(a1), "v"(b))
+#define HP3D_MFMA16B_PAIR_FIRST(REG, acc0, acc1, a0, a1, b)                                                         \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %2, %4, 0\n\t"                                                      \
+                 "v_mfma_f32_16x16x32_bf16 %1, %3, %4, 0"                                                            \
+                 : "=&" REG(acc0), "=&" REG(acc1)                                                                   \
+                 : "v"(a0), "v"(a1), "v"(b))
+// two wait states in front of an asm MFMA whose A / B operand a VALU instruction has just written (the hazard recogniser cannot see the MFMA)
+#define HP3D_MFMA_OPERAND_FENCE() asm volatile("s_nop 1")
 // conv_wino7.hip: two products on two accumulators (one k quad each) -- neither MFMA waits for its predecessor; accumulators pinned to AGPRs
 #define HP3D_MFMA16_X2(acc0, acc1, a0e, a1e, b0e, b1e)                                                              \
     asm volatile("v_mfma_f32_16x16x4_f32 %0, %2, %4, %0\n\t"                                                       \
@@ -313,6 +334,13 @@ size_t wino4_packed_floats(int k, int cin_pad, int cout_pad);
 void wino4_pack_weights(const float* g_hwio, int k, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst);
 int conv_wino4_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* ksplit);
 int conv_wino4_launch(const ConvParams& p, int pool, hipStream_t s);
+// conv_wino4s.hip (round 6): the same F(4x4,3x3) with the plane products on v_mfma_f32_16x16x32_bf16 over three bfloat16 pieces per
+// operand (six products, f32 accumulate); filters pre-split, 6 bytes per value: [36][step][Cout/64][4]{[U1|U0] 16 B x 64 lanes, U2 8 B x 64 lanes}
+size_t wino4s_packed_bytes(int cin_pad, int cout_pad);
+void wino4s_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, void* dst);
+int conv_wino4s_eligible(int k, int stride, int Cin, int Cout, int Ho, int Wo, int B, int in_cs, int out_cs, int pool, int* filled);
+int conv_wino4s_launch(const ConvParams& p, int pool, hipStream_t s);
+size_t conv_wino4s_tail_floats();
 // scratch (floats) the tail pieces of any conv_wino4 launch can need: two 32-tile x 64-cout blocks of raw 4x4 outputs per CU
 size_t conv_wino4_tail_floats();
 // conv_wino7.hip: the 7x7 layers as Winograd F(4x4,4x4) over the filter's four 4x4-tap blocks (49 planes, V shared by the blocks);

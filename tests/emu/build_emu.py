@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, 'hand3d_amd', 'csrc')
 LIB = os.path.join(HERE, 'libhp3d_emu.so')
-SRCS = [os.path.join(CSRC, f) for f in ('conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip')] + [os.path.join(HERE, 'hp3d_emu.cpp')]
+SRCS = [os.path.join(CSRC, f) for f in ('conv_mfma.hip', 'conv_wino.hip', 'conv_wino2.hip', 'conv_wino4.hip', 'conv_wino4s.hip', 'conv_wino7.hip', 'conv_pw2.hip', 'conv_first.hip', 'conv_h16.hip', 'glue.hip', 'lift_fused.hip', 'engine.hip')] + [os.path.join(HERE, 'hp3d_emu.cpp')]
 DEPS = SRCS + [os.path.join(CSRC, 'hp3d_common.h'), os.path.join(CSRC, 'lift_fused.h'), os.path.join(CSRC, 'wino4_shared.h'), os.path.join(CSRC, 'wino4_diag.h'), os.path.join(HERE, 'hp3d_emu.h'), os.path.join(ROOT, 'include', 'hp3d.h')]
 
 

@@ -177,6 +177,37 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c) {
     return c;
 }
 
+f32x4 hp3d_emu_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c) {
+    const unsigned tid = g_blk.cur->tid;
+    WaveX& w = g_blk.waves[tid >> 6];
+    const int lane = tid & 63, slot = w.gen & 1;
+    memcpy(&w.a4[slot][lane], &a, 16);
+    memcpy(&w.b4[slot][lane], &b, 16);
+    wave_rendezvous(w, 64);
+    // v_mfma_f32_16x16x32_bf16: A[i][k] in lane i + 16 (k / 8), element k % 8 (two bfloat16 per register, the lower k in bits 0..15);
+    // B[k][j] likewise; D as the f32 16x16x4 form.  Products of bfloat16 are exact in float32; the 32 products + C are summed wide and
+    // rounded once (the hardware's internal order and width are not specified -- tests use tolerances that cover it).
+    const int col = lane & 15, hi = lane >> 4;
+    auto bf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; };
+    float bcol[32];
+    for (int g = 0; g < 4; ++g) {
+        unsigned short bh[8];
+        memcpy(bh, &w.b4[slot][col + 16 * g], 16);
+        for (int j = 0; j < 8; ++j) bcol[8 * g + j] = bf(bh[j]);
+    }
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * hi + r;
+        double d = c[r];
+        for (int g = 0; g < 4; ++g) {
+            unsigned short ah[8];
+            memcpy(ah, &w.a4[slot][row + 16 * g], 16);
+            for (int j = 0; j < 8; ++j) d += (double)(bf(ah[j]) * bcol[8 * g + j]);
+        }
+        c[r] = (float)d;
+    }
+    return c;
+}
+
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask) {
     const unsigned tid = g_blk.cur->tid;
     WaveX& w = g_blk.waves[tid >> 6];

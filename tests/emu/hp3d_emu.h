@@ -22,6 +22,14 @@ typedef float f32x16 __attribute__((vector_size(64)));
 typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((vector_size(16)));
 typedef _Float16 f16x4 __attribute__((vector_size(8)));
+typedef unsigned u32x4 __attribute__((vector_size(16)));
+// two float32 -> two bfloat16, round to nearest even (v_cvt_pk_bf16_f32); `lo` in bits 0..15
+static inline unsigned hp3d_emu_bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;      // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static inline unsigned hp3d_cvt_pk_bf16(float lo, float hi) { return hp3d_emu_bf16_rne(lo) | (hp3d_emu_bf16_rne(hi) << 16); }
 // wave-level LDS rendezvous: lanes are fibers here and need a real yield point (use only where the trip count is uniform
 // over the workgroup)
 #define HP3D_WAVE_LDS_SYNC() __syncthreads()
@@ -173,6 +181,19 @@ f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
         const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                    \
         (acc0) = _z; (acc1) = _z;                                                 \
         HP3D_MFMA16_2x4_UNLESS(acc0, acc1, a0, a1, b4, 0);                        \
+    } while (0)
+#define HP3D_MFMA_OPERAND_FENCE() ((void)0)
+f32x4 hp3d_emu_mfma_16x16x32_bf16(u32x4 a, u32x4 b, f32x4 c);
+#define HP3D_MFMA16B_PAIR(REG, acc0, acc1, a0, a1, b)                                   \
+    do {                                                                              \
+        (acc0) = hp3d_emu_mfma_16x16x32_bf16((a0), (u32x4)(b), (acc0));               \
+        (acc1) = hp3d_emu_mfma_16x16x32_bf16((a1), (u32x4)(b), (acc1));               \
+    } while (0)
+#define HP3D_MFMA16B_PAIR_FIRST(REG, acc0, acc1, a0, a1, b)                             \
+    do {                                                                              \
+        const f32x4 _z = {0.f, 0.f, 0.f, 0.f};                                        \
+        (acc0) = _z; (acc1) = _z;                                                     \
+        HP3D_MFMA16B_PAIR(REG, acc0, acc1, a0, a1, b);                                \
     } while (0)
 unsigned long long hp3d_emu_shfl_xor_u64(unsigned long long v, int mask);
 inline unsigned long long __shfl_xor(unsigned long long v, int mask) { return hp3d_emu_shfl_xor_u64(v, mask); }

@@ -99,7 +99,8 @@ def test_fp_contraction_is_confined_to_the_winograd_f4x4_kernel(tmp_path):
     from hand3d_amd import build as hb
     assert '-ffp-contract=off' in hb.FLAGS and not any('contract=fast' in f for f in hb.FLAGS)
     # (conv_wino7.hip: the F(4x4,4x4) form of the 7x7 layers -- its transforms multiply by 2, 4, 5, 1/2 ... too, same reason)
-    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip', 'conv_wino7.hip'}, "another file with its own floating-point flags: extend this test before adding it"
+    # (conv_wino4s.hip, round 6: the split-operand form of conv_wino4.hip -- the same transforms; its bf16 x3 split is subtractions only)
+    assert set(hb.EXTRA_FLAGS) == {'conv_wino4.hip', 'conv_wino4s.hip', 'conv_wino7.hip'}, "another file with its own floating-point flags: extend this test before adding it"
     assert '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino4.hip'] and '-ffp-contract=fast' in hb.EXTRA_FLAGS['conv_wino7.hip']
     pat = re.compile(r'seg_upsample_softmax|seg_softmax|mask_grow|crop_and_resize|resize_bilinear|preprocess_u8|kp_detect|argmax2d')
     fused = re.compile(r'v_(fma|fmac|mad|pk_fma)_f32')

@@ -178,7 +178,7 @@ def oracle_leg(weights, imgs, hs, gpu_out, workload, budget_s, alg_flop_per_imag
     return cpu, par
 
 
-CONV_FAMILIES = ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3', 'conv_pw2')
+CONV_FAMILIES = ('conv_wino', 'conv_wino2', 'conv_wino4', 'conv_wino4s', 'conv_mfma', 'conv_h16', 'conv_first_3x3_c3', 'conv_pw2')
 
 
 def families(rows):
@@ -188,7 +188,8 @@ def families(rows):
     7x7 and 1x1 forms), conv_first (conv1_1), conv_pw2 (the 1x1 head pairs as one launch), everything else under its own kernel name."""
     fam = {}
     for name, kern, ms, fl, by in rows:
-        k = ('conv_wino4' if kern.startswith(('conv_wino4', 'conv_wino7')) else 'conv_wino2' if kern.startswith('conv_wino2') else
+        k = ('conv_wino4s' if kern.startswith('conv_wino4s') else
+             'conv_wino4' if kern.startswith(('conv_wino4', 'conv_wino7')) else 'conv_wino2' if kern.startswith('conv_wino2') else
              'conv_wino' if kern.startswith('conv_wino') else 'conv_mfma' if kern.startswith('conv_mfma') else
              'conv_h16' if kern.startswith('conv_h16') else 'conv_first_3x3_c3' if kern.startswith('conv_first') else
              'conv_pw2' if kern.startswith('conv_pw2') else kern)
@@ -199,7 +200,10 @@ def families(rows):
         # their structurally zero planes: (4*36 + 4*30 + 25) = 289 plane products per 16*49
         # conv_wino7 (F(4x4,4x4) over the 7x7 filter's four 4x4-tap blocks, round 5; counted in the conv_wino4 family = "Winograd with 4x4
         # output tiles on the f32 matrix cores"): (49 + 42 + 42 + 36) = 169 plane products per 16*49
-        exe = ((169.0 / 784.0 if kern.startswith('conv_wino7') else 289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
+        # conv_wino4s (round 6: the same F(4x4,3x3) on the bf16 matrix pipe, three bfloat16 pieces per operand, SIX products per float32 product):
+        # 6 * 36/144 bf16 multiply-adds per direct-form multiply-add, priced against the dense bf16 peak
+        exe = (6.0 * 36.0 / 144.0 if k == 'conv_wino4s' else
+               (169.0 / 784.0 if kern.startswith('conv_wino7') else 289.0 / 784.0 if 'as7x7' in kern else 36.0 / 144.0) if k == 'conv_wino4' else
                (121.0 / 196.0 if 'as7x7' in kern else 16.0 / 36.0) if k in ('conv_wino', 'conv_wino2') else 1.0)
         f = fam.setdefault(k, [0.0, 0.0, 0.0, 0, 0.0])
         # (conv_first_touch: the read pass that warms the memory-side cache for conv1_1's gathers -- its TIME belongs to the family, it is no launch
@@ -268,7 +272,7 @@ def measure_config(eng, tag, what, call_site, workload, B, H, W, steps, warmup, 
     fam, total_ms = families(rows)
     conv = [k for k in fam if k in CONV_FAMILIES]
     dom = max(conv, key=lambda k: fam[k][0])
-    roof = roof_of_family(fam, dom, total_ms, PEAK_F32_MFMA_TFLOPS if dtype == 'f32' else PEAK_F16_MFMA_TFLOPS)
+    roof = roof_of_family(fam, dom, total_ms, PEAK_F32_MFMA_TFLOPS if dtype == 'f32' and dom != 'conv_wino4s' else PEAK_F16_MFMA_TFLOPS)
     fl = arch.pipeline_flops(H, W)
     rec = {"config": tag, "what": what, "call_site": call_site, "dtype": dtype, "batch": B, "height": H, "width": W,
            "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
@@ -303,12 +307,27 @@ def other_configs_measure(eng, weights, a, device):
         ('C1', 'run.py forward pass shape: inference(), B=1, 240x320, f32', 'run.py:44-46', 'full', 1, 240, 320, 50, 10, 0),
         ('C2', 'PoseNet2D only on a ground-truth crop: inference_pose2d(), B=1, 256x256, f32', 'eval2d_gt_cropped.py:44-46', 'posenet', 1, 256, 256, 50, 10, 100),
         ('C4-shard@240x320', "config 4's per-GPU shard at eval_full.py's input size: inference(), B=32, 240x320, f32", 'eval_full.py:50-57', 'full', 32, 240, 320, 10, 3, 300),
+        # round 6: the primary line's workload with the split-operand kernel on (conv_wino4s.hip: the filled 3x3 layers with
+        # Cin >= 128 on v_mfma_f32_16x16x32_bf16, three bfloat16 pieces per operand, six products, float32 accumulate).  An OPTION, not the
+        # headline: its per-layer error is not below conv_wino4's on every shape (profiles/r06_split_numerics.md)
+        ('C3-split', "the primary workload with option wino4_split=auto: inference(), B=32, 320x320, f32 in / out, 3x3 layers with Cin >= 128 as "
+         "bf16x3 split operands (6 products, f32 accumulate)", 'eval2d.py:50-58', 'full', 32, 320, 320, 10, 3, 200, {'wino4_split': ('auto', '0')}),
     ]
-    for tag, what, site, workload, B, H, W, steps, warmup, seed in plan:
+    for entry in plan:
+        tag, what, site, workload, B, H, W, steps, warmup, seed = entry[:10]
+        opts = entry[10] if len(entry) > 10 else {}
         try:
             img = synth.make_batch(seed, B, H, W)
             hs = synth.hand_sides(B)
-            rec, out = measure_config(eng, tag, what, site, workload, B, H, W, steps, warmup, 'f32', img, hs)
+            for key, (on, _off) in opts.items():
+                eng.set_option(key, on)
+            try:
+                rec, out = measure_config(eng, tag, what, site, workload, B, H, W, steps, warmup, 'f32', img, hs)
+            finally:
+                for key, (_on, off) in opts.items():
+                    eng.set_option(key, off)
+            if opts:
+                rec["options"] = {key: on for key, (on, _off) in opts.items()}
             rec["parity_spot"] = None
             res.append(rec)
             keep.append((rec, workload, img[0:1].copy(), hs[0:1].copy(), out))
@@ -623,7 +642,7 @@ def main():
         peak = PEAK_F32_MFMA_TFLOPS if a.dtype == 'f32' else PEAK_F16_MFMA_TFLOPS
 
         def roof_of(k):
-            return roof_of_family(fam, k, total_ms, peak)
+            return roof_of_family(fam, k, total_ms, PEAK_F16_MFMA_TFLOPS if k == 'conv_wino4s' else peak)
         dom = max(fam, key=lambda k: fam[k][0])
         roof = roof_of(dom)
         if dom == 'conv_h16':
@@ -632,6 +651,10 @@ def main():
         if dom in ('conv_wino', 'conv_wino2'):
             roof["note"] = ("float32 Winograd F(2x2,3x3): executes 16/36 of the direct-form multiply-adds (7x7 layers as nine 3x3 "
                             "blocks without their structurally zero planes: 121/196); frac is the executed matrix-core rate over the dense f32 MFMA peak")
+        if dom == 'conv_wino4s':
+            roof["note"] = ("Winograd F(4x4,3x3) with split operands (option wino4_split, conv_wino4s.hip): three bfloat16 pieces per operand, six products per "
+                            "float32 product on v_mfma_f32_16x16x32_bf16, float32 accumulate -- executes 6 * 36/144 bf16 multiply-adds per direct-form "
+                            "multiply-add; frac is that rate over the dense bf16 MFMA peak")
         if dom == 'conv_wino4':
             roof["note"] = ("float32 Winograd with 4x4 output tiles: F(4x4,3x3) (conv_wino4.hip) executes 36/144 of the direct-form multiply-adds; "
                             "the 7x7 layers run as F(4x4,4x4) over the filter's four 4x4-tap blocks (conv_wino7.hip, kernel conv_wino7_*: 169/784 "

@@ -36,12 +36,6 @@
 #include <type_traits>
 
 #define W4S_WLOAD HP3D_BUFFER_LOAD8
-// -DHP3D_W4S_ABL=<bit mask>: timing ablations (builds that compute WRONG results on purpose; profiles/r06_tuning_notes.md section 2):
-//   1 no filter loads in the step loop | 2 no window loads | 4 no split (raw bits as fragments) | 8 no MFMAs | 16 no epilogue |
-//   32 no input transform / V writes | 64 no fragment reads from LDS
-#ifndef HP3D_W4S_ABL
-#define HP3D_W4S_ABL 0
-#endif
 
 namespace {
 
@@ -157,9 +151,7 @@ void conv_wino4s_kernel(const ConvParams p) {
     f32x4 bq[W4S_RING];           // [U1|U0]: registers 0..1 = piece 1 of channels 4 q .. 4 q + 3, registers 2..3 = piece 0
     f32x2 bq2[W4S_RING];          // U2
     f32x4 b02;                    // [U0|U2] of the cout block whose second product comes next (built one gap ahead: see the hazard note below)
-    bool in_loop = false;
     auto b_fetch = [&](int slot, int soff) {
-        if ((HP3D_W4S_ABL & 1) && in_loop) return;
         bq[slot] = HP3D_BUFFER_LOAD16(wrsrc, bv16, soff);
         bq2[slot] = HP3D_BUFFER_LOAD8(wrsrc, bv8, soff);
     };
@@ -168,7 +160,6 @@ void conv_wino4s_kernel(const ConvParams p) {
     f32x4 raw[2][2];              // [set][tile block]: V of channels 4 q .. 4 q + 3, float32
     u32x4 fa10[2][2], fa02[2][2]; // [set][tile block]: [V1|V0], [V0|V2]
     auto a_fetch = [&](int set, int j) {
-        if ((HP3D_W4S_ABL & 64) && in_loop) return;
 #pragma unroll
         for (int m = 0; m < 2; ++m) raw[set][m] = *(const f32x4*)((const char*)V + ab + (j * W4S_PLANE_FLOATS + m * 16 * W4S_CK) * 4);
     };
@@ -177,10 +168,6 @@ void conv_wino4s_kernel(const ConvParams p) {
     float sh[4], sr[4];
     auto split_stage = [&](int st, int set, int m) {
         const f32x4 x = raw[set][m];
-        if (HP3D_W4S_ABL & 4) {
-            if (st == 5) { fa10[set][m] = __builtin_bit_cast(u32x4, x); fa02[set][m] = __builtin_bit_cast(u32x4, x); HP3D_OPAQUE_V(fa10[set][m]); HP3D_OPAQUE_V(fa02[set][m]); }
-            return;
-        }
         if (st == 0) { sp1[0] = hp3d_cvt_pk_bf16(x[0], x[1]); sp1[1] = hp3d_cvt_pk_bf16(x[2], x[3]); sh[0] = w4s_lo16(sp1[0]); sh[1] = w4s_hi16(sp1[0]); }
         if (st == 1) { sh[2] = w4s_lo16(sp1[1]); sh[3] = w4s_hi16(sp1[1]); sr[0] = x[0] - sh[0]; sr[1] = x[1] - sh[1]; }
         if (st == 2) { sr[2] = x[2] - sh[2]; sr[3] = x[3] - sh[3]; sp2[0] = hp3d_cvt_pk_bf16(sr[0], sr[1]); sp2[1] = hp3d_cvt_pk_bf16(sr[2], sr[3]); }
@@ -243,7 +230,6 @@ void conv_wino4s_kernel(const ConvParams p) {
     for (int pl = 0; pl < W4_NP; ++pl) v_write(0, pl);
     __syncthreads();
     int cur = 0;
-    in_loop = true;
 
     for (int k = 0;; ++k) {
         int n_cy = cy, n_tblock = tblock, n_s0 = s0, n_s1 = s1, n_piece = -1;
@@ -279,9 +265,7 @@ void conv_wino4s_kernel(const ConvParams p) {
                 for (int g = 0; g < 12; ++g) {        // twelve MFMA pairs (both tile blocks): cout block g / 3, product g % 3
                     const int c = g / 3, pr = g % 3, q = j * W4S_CB + c, bs = q % W4S_RING;
                     HP3D_SCHED_BARRIER();
-                    if (HP3D_W4S_ABL & 8) {
-                        if (FIRST && pr == 0) { M[j][0][c] = f32x4{0.f, 0.f, 0.f, 0.f}; M[j][1][c] = M[j][0][c]; }
-                    } else if (pr == 0) {
+                    if (pr == 0) {
                         if (FIRST) {
                             if (j < 8) HP3D_MFMA16B_PAIR_FIRST("a", M[j][0][c], M[j][1][c], fa10[as][0], fa10[as][1], bq[bs]);
                             else HP3D_MFMA16B_PAIR_FIRST("v", M[j][0][c], M[j][1][c], fa10[as][0], fa10[as][1], bq[bs]);
@@ -316,12 +300,12 @@ void conv_wino4s_kernel(const ConvParams p) {
                         else b_fetch(bs, soff_of(t - W4S_SLOTS, nstep, ncy_));
                     }
                     if (g == 11 && j + 2 < W4S_WP) a_fetch(as, j + 2);               // (its set was consumed by this plane's split one plane ago)
-                    if (!(HP3D_W4S_ABL & 2) && j < W4S_WINDOW_PLANES && g < 9) {      // next step's window: 9 loads behind each of the first four planes
+                    if (j < W4S_WINDOW_PLANES && g < 9) {                             // next step's window: 9 loads behind each of the first four planes
                         const int we = W4_ISSUE_ELEM(j * 9 + g);
                         d[we] = W4S_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
                     }
-                    if (!(HP3D_W4S_ABL & 32) && j >= W4S_TRANSFORM_FIRST && j < W4S_TRANSFORM_FIRST + 3 && g % 3 == 0) transform_pass((j - W4S_TRANSFORM_FIRST) * 4 + g / 3);
-                    if (!(HP3D_W4S_ABL & 32) && j == W4S_WP - 1) {                    // V of the next step: three values behind each pair of the last plane
+                    if (j >= W4S_TRANSFORM_FIRST && j < W4S_TRANSFORM_FIRST + 3 && g % 3 == 0) transform_pass((j - W4S_TRANSFORM_FIRST) * 4 + g / 3);
+                    if (j == W4S_WP - 1) {                                            // V of the next step: three values behind each pair of the last plane
 #pragma unroll
                         for (int i = 0; i < 3; ++i) v_write(cur ^ 1, g * 3 + i);
                     }
@@ -361,7 +345,7 @@ void conv_wino4s_kernel(const ConvParams p) {
 #pragma unroll
         for (int mm = 0; mm < 2; ++mm) { toff[mm] = tab[2 * tp + mm]; tfl[mm] = tab[W4S_TILES + 2 * tp + mm]; }
 #pragma unroll
-        for (int c = 0; c < ((HP3D_W4S_ABL & 16) ? 1 : W4S_CB); ++c) {
+        for (int c = 0; c < W4S_CB; ++c) {
 #pragma unroll
             for (int j = 0; j < W4S_WP; ++j)
 #pragma unroll

@@ -1,6 +1,7 @@
 """VALU -> MFMA operand hazard check over a hipcc -S listing (or llvm-objdump -d output): an MFMA that reads, as SrcA / SrcB, a VGPR
-written by a VALU instruction fewer than `need` issue slots earlier sees the old value on gfx950 (measured: scripts/micro/split_unit.hip;
-hipcc covers it for its own MFMAs, but not for MFMAs inside inline-asm statements).  Prints every violation; exit code 1 if any.
+written by a VALU instruction fewer than `need` = 2 wait states earlier sees the OLD value on gfx950 (measured:
+scripts/micro/mfma_operand_hazard.hip; hipcc pads its own MFMAs with s_nop 1, but cannot see MFMAs inside inline-asm statements).
+Prints every violation; exit code 1 if any.
 usage: python scripts/mfma_hazard_check.py file.s [kernel-substring] [need=2]"""
 import re
 import sys
@@ -16,22 +17,27 @@ def regs(tok):
 
 
 def check(lines, need=2):
-    """lines: instruction strings of ONE kernel in program order (labels / directives removed). Returns the violations."""
+    """lines: instruction strings of ONE kernel in program order (labels / directives removed).  A VALU write of an MFMA's SrcA / SrcB register
+    needs `need` wait states in front of the MFMA (measured on MI355X, scripts/micro/mfma_operand_hazard.hip: with 0 or 1 the MFMA reads the
+    OLD value, with 2 the new one; an instruction is one wait state, `s_nop N` is N + 1 -- hipcc pads its own MFMAs with `s_nop 1`).
+    Returns the violations as (index of the MFMA, wait states found, the VALU instruction, the MFMA)."""
     bad = []
     for i, l in enumerate(lines):
         if not l.startswith('v_mfma'):
             continue
         ops = [t.strip() for t in l.split(None, 1)[1].split(',')]
         src = regs(ops[1]) | regs(ops[2])
-        for back in range(1, need + 1):
-            if i - back < 0:
-                break
-            p = lines[i - back]
-            if not p.startswith('v_') or p.startswith('v_mfma') or p.startswith('v_cmp') or p.startswith('v_readfirstlane') or p.startswith('v_readlane'):
-                continue
-            dst = regs(p.split(None, 1)[1].split(',')[0].strip())
-            if dst & src:
-                bad.append((i, back, p, l))
+        states = 0
+        k = i - 1
+        while k >= 0 and states < need:
+            p = lines[k]
+            if p.startswith('v_') and not p.startswith(('v_mfma', 'v_cmp', 'v_readfirstlane', 'v_readlane')):
+                dst = regs(p.split(None, 1)[1].split(',')[0].strip())
+                if dst & src:
+                    bad.append((i, states, p, l))
+            m = re.match(r's_nop\s+(\d+)', p)
+            states += int(m.group(1)) + 1 if m else 1
+            k -= 1
     return bad
 
 
@@ -65,6 +71,6 @@ if __name__ == '__main__':
         n_mfma = sum(1 for l in lines if l.startswith('v_mfma'))
         print('%s: %d MFMAs, %d violations' % (name[:100], n_mfma, len(bad)))
         for i, back, p, l in bad[:10]:
-            print('   #%d: "%s"  %d slot(s) before  "%s"' % (i, p, back, l))
+            print('   #%d: "%s"  with %d wait state(s) in front of  "%s"' % (i, p, back, l))
         total += len(bad)
     sys.exit(1 if total else 0)

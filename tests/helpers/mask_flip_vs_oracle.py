@@ -43,9 +43,11 @@ if cache is not None:
 e = Engine(0)
 e.load_weight_dict(w)
 e.finalize_weights()
-modes = [('direct kernel everywhere (fmaf chain)', {'conv_impl': 'direct', 'wino4': '0', 'wino2': '0'}),
-         ('F(2x2,3x3) (conv_wino.hip)', {'conv_impl': 'mfma', 'wino4': '0', 'wino2': '0'}),
-         ('F(4x4,3x3) (conv_wino4.hip, the default)', {'conv_impl': 'mfma', 'wino4': 'all', 'wino2': 'auto'})]
+modes = [('direct kernel everywhere (fmaf chain)', {'conv_impl': 'direct', 'wino4': '0', 'wino2': '0', 'wino4_split': '0'}),
+         ('F(2x2,3x3) (conv_wino.hip)', {'conv_impl': 'mfma', 'wino4': '0', 'wino2': '0', 'wino4_split': '0'}),
+         ('F(4x4,3x3) (conv_wino4.hip, the default)', {'conv_impl': 'mfma', 'wino4': 'all', 'wino2': 'auto', 'wino4_split': '0'}),
+         # round 6: the same with the filled Cin >= 128 layers on the bf16 matrix pipe, three bfloat16 pieces per operand (conv_wino4s.hip)
+         ('F(4x4,3x3), split bf16x3 operands where eligible (option wino4_split=auto)', {'conv_impl': 'mfma', 'wino4': 'all', 'wino2': 'auto', 'wino4_split': 'auto'})]
 stat = {m[0]: dict(img_det=0, img_mask=0, img_box=0, px_det=0, margin=0.0, sm_err=0.0) for m in modes}
 t0 = time.time()
 e.set_option('streams', '1')
@@ -79,6 +81,7 @@ for b0 in range(0, n_img, CH):
     print('%d / %d images, %.0f s' % (b0 + nb, n_img, time.time() - t0), flush=True)
 for k in ('conv_impl', 'wino4', 'wino2', 'streams'):
     e.set_option(k, 'auto' if k != 'conv_impl' else 'mfma')
+e.set_option('wino4_split', '0')
 lines = ['| engine mode | images with a det pixel != oracle | det pixels != oracle (of %d) | largest oracle margin abs(s1 - s0) at such a pixel | images with another mask | images with another crop box | worst score-map error |' % (n_img * 320 * 320),
          '|---|---|---|---|---|---|---|']
 for name, _ in modes:

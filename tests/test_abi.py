@@ -128,6 +128,35 @@ def test_fp_contraction_is_confined_to_the_winograd_f4x4_kernel(tmp_path):
     assert shipped == off, "the shipped glue kernels are not the -ffp-contract=off build: %r vs %r" % (shipped, off)
 
 
+def test_asm_mfmas_do_not_read_operands_a_valu_instruction_just_wrote(tmp_path):
+    """Round 6 (scripts/micro/split_unit.hip, measured on MI355X): an MFMA whose SrcA / SrcB register was written by a VALU instruction fewer
+    than two issue slots earlier reads the OLD value.  hipcc pads its own MFMAs, but cannot look into the inline-asm statements that hold
+    this engine's (accumulators pinned to AGPRs) -- the first build of conv_wino4s.hip returned NaNs on the GPU while the CPU interpreter of
+    the same source was right.  So every kernel of the SHIPPED code object is checked: two wait states between a VALU write of an MFMA operand
+    and the MFMA (scripts/mfma_hazard_check.py, rule measured by scripts/micro/mfma_operand_hazard.hip; conv_wino4s.hip builds its fragments
+    one MFMA pair ahead for that reason; hipcc's own `s_nop 1` in front of compiler-made MFMAs counts)."""
+    sys.path.insert(0, os.path.join(ROOT, 'scripts'))
+    try:
+        import mfma_hazard_check as hz
+    finally:
+        sys.path.pop(0)
+    kernels = _kernel_disassembly(tmp_path)
+    n_checked = 0
+    for name, ins in kernels.items():
+        lines = [re.sub(r'\s*//.*$', '', l).strip() for l in ins]
+        lines = [l for l in lines if l and not l.endswith(':')]
+        if not any(l.startswith('v_mfma') for l in lines):
+            continue
+        n_checked += 1
+        bad = hz.check(lines, need=2)
+        assert not bad, "%s: %d MFMA operand hazards, e.g. %r" % (name, len(bad), bad[0][2:])
+    assert n_checked >= 20 and any('conv_wino4s' in k for k in kernels), n_checked
+    # (the checker sees a planted violation)
+    assert hz.check(['v_mov_b32_e32 v9, v3', 's_nop 0', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
+    assert not hz.check(['v_mov_b32_e32 v9, v3', 's_nop 1', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
+    assert not hz.check(['v_mov_b32_e32 v9, v3', 'v_add_u32_e32 v1, v2, v3', 'ds_read_b64 v[20:21], v1', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
+
+
 def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_path):
     """The miscompile of round 2 (profiles/r02_tuning_notes.md, "conv_wino"): when hipcc cannot prove a buffer load's scalar offset
     wave-uniform it wraps the load in a waterfall loop (v_readfirstlane ... s_and_saveexec ... s_cbranch_execnz), and one such build
@@ -136,7 +165,7 @@ def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_p
     (no waterfall loop), and (b) no scratch access lies inside the MFMA phase of a step / chunk loop (a spilled accumulator or
     address there drains the weight ring and has produced the slow builds recorded in the tuning notes)."""
     kernels = _kernel_disassembly(tmp_path)
-    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino[247]?_kernel|conv_h16_kernel', k)}
+    hot = {k: v for k, v in kernels.items() if re.search(r'conv_wino(2|4|4s|7)?_kernel|conv_h16_kernel', k)}
     assert len(hot) >= 10 and any('conv_wino7' in k for k in hot), sorted(kernels)[:20]
     for name, ins in hot.items():
         ops = [l.split('//')[0].split()[0] if l.split('//')[0].split() else '' for l in ins]

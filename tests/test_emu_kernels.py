@@ -331,6 +331,46 @@ def test_winograd_kernel_on_interpreter(emu_engine, case):
     assert np.abs(y - r).max() < 1e-5 and np.abs(ys - r).max() < 1e-5
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 128, 0), (3, 18, 22, 48, 128, 1), (1, 30, 40, 256, 128, 0), (4, 13, 11, 16, 64, 0), (2, 32, 32, 128, 64, 1),
+                                  (1, 7, 9, 128, 64, 0), (3, 10, 6, 16, 64, 1)], ids=lambda c: "B%d_%dx%d_%d-%d_p%d" % c)
+def test_winograd_f4x4_split_operands_on_interpreter(emu_engine, case):
+    """conv_wino4s.hip (option wino4_split = 1): F(4x4,3x3) with the plane products on v_mfma_f32_16x16x32_bf16 over three bfloat16 pieces per
+    operand.  Held on the interpreter: the pre-split filter layout ([U1|U0] + U2 fragments), the plane-per-wave accumulators and their
+    exchange through LDS in the epilogue (swizzled [plane][cout][tile]), pooled / ragged / multi-image tiles, items that run as tail pieces;
+    the result against the float64 oracle within conv_wino4's gate and close to conv_wino4's own (the interpreter sums an MFMA's 32 products
+    wide and rounds once: the hardware's order is its own, the GPU test holds the gate there)."""
+    B, H, W, Cin, Cout, pool = case
+    rng = np.random.default_rng(sum(case))
+    x = rng.standard_normal((B, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    r = T.leaky_relu(T.bias_add(T.conv2d_same(x, w, 1, acc=np.float64), b))
+    if pool:
+        r = T.max_pool_2x2(r)
+    emu_engine.set_option('wino4', '1')
+    try:
+        y4 = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        emu_engine.set_option('wino4', 'auto')
+    emu_engine.set_option('wino4_split', '1')
+    try:
+        n0, t0 = emu_engine.counter('conv_wino4s_launches'), emu_engine.counter('conv_wino4s_tail_launches')
+        y = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+        assert emu_engine.counter('conv_wino4s_launches') == n0 + 1
+        tails = emu_engine.counter('conv_wino4s_tail_launches') - t0
+        emu_engine.set_option('wino4_tail', '0')
+        y_nt = emu_engine.conv2d(x, w, b, 1, True, bool(pool))
+    finally:
+        emu_engine.set_option('wino4_split', '0')
+        emu_engine.set_option('wino4_tail', '1')
+    err, err4 = np.abs(y - r).max(), np.abs(y4 - r).max()
+    print('conv_wino4s %s: %.2e (conv_wino4 %.2e), tail pieces %d' % (case, err, err4, tails))
+    assert y.shape == r.shape and err < 2e-4 and np.abs(y - y4).max() < 1e-4
+    assert np.abs(y_nt - r).max() < 2e-4          # whole items only: the same sums in another order
+    if case in ((2, 16, 32, 64, 128, 0), (2, 32, 32, 128, 64, 1), (1, 7, 9, 128, 64, 0)):
+        assert tails == 1, "this shape leaves an under-filled last round on the interpreter's 3 CUs: it must run as tail pieces"
+
+
 @pytest.mark.parametrize("case", [(1, 12, 14, 32, 128, 0), (2, 9, 11, 40, 64, 1)], ids=lambda c: "B%d_%dx%d_%d-%d_a%d" % c)
 def test_winograd_7x7_as_3x3_blocks_on_interpreter(emu_engine, case):
     """7x7 filter on conv_wino.hip: nine 3x3 blocks of the zero-extended 9x9 filter accumulate into the same planes

@@ -753,6 +753,12 @@ def main():
             res["config"]["hipgraph_replays"] = eng.counter('graph_replays')
         os.write(json_fd, (json.dumps(res) + '\n').encode())
     sp.close()
+    if sp.comm_abandoned:
+        # an RCCL set-up call is still stuck in its worker thread: tearing the engine down (hipStreamDestroy, library destructors) could
+        # wait on whatever that call holds -- the line is out, leave without the destructors
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == '__main__':

@@ -17,6 +17,7 @@ import hashlib
 import hmac
 import os
 import socket
+import threading
 import struct
 import time
 
@@ -330,36 +331,79 @@ class ShardedPipeline(object):
         if self.rdzv is None:
             raise ValueError("world > 1 needs a Rendezvous (Rendezvous.from_env())")
         self.comm_ready = False
+        self.comm_abandoned = False   # a set-up call ran into its deadline: the communicator is left alone for good
         self.tcp_only = False         # set by use_tcp_only(): gathers travel over the rendezvous sockets, not RCCL
 
     def use_tcp_only(self):
         """Degraded mode for a box whose RCCL communicator cannot be built: every rank loads its own weights and the (tiny)
         per-step keypoint gather travels over the rendezvous' TCP sockets.  Must be entered by ALL ranks."""
-        if self.comm_ready:
+        if self.comm_ready and not self.comm_abandoned:
             try:
                 self.engine.comm_destroy()
             except Exception:
                 pass
-            self.comm_ready = False
+        self.comm_ready = False
         self.tcp_only = True
 
+    def _with_deadline(self, what, fn, *args):
+        """RCCL calls that set a communicator up (ncclCommInitRank, the first broadcast) have been seen neither to return nor to fail
+        (profiles/r05_tuning_notes.md section 15: two ranks on one device); at eight ranks that is the launcher's 1800 s and no JSON
+        line.  So they run in a worker thread (ctypes releases the GIL for the call) and the caller waits at most HP3D_RCCL_TIMEOUT
+        seconds (default 120; 0 = wait forever).  On expiry a TimeoutError whose text starts with "rccl init timeout" is raised: the
+        caller (bench.py) then agrees with the other ranks over the rendezvous and takes the TCP path.  The stuck call is abandoned:
+        its thread is a daemon, and the communicator is never touched again (close() does not destroy it)."""
+        timeout = float(os.environ.get('HP3D_RCCL_TIMEOUT', '120'))
+        if timeout <= 0:
+            return fn(*args)
+        box = {}
+
+        def run():
+            try:
+                box['value'] = fn(*args)
+            except BaseException as e:          # noqa: B902 -- handed to the waiting thread as it is
+                box['error'] = e
+        t = threading.Thread(target=run, name='hp3d-' + what, daemon=True)
+        t.start()
+        t.join(timeout)
+        if t.is_alive():
+            self.comm_abandoned = True
+            raise TimeoutError("rccl init timeout: %s did not return within %.0f s on rank %d of %d (HP3D_RCCL_TIMEOUT)" % (what, timeout, self.rank, self.world))
+        if 'error' in box:
+            raise box['error']
+        return box.get('value')
+
     def comm_init(self):
-        """hp3d_comm_init on every rank: rank 0 draws the 128-byte id, the rendezvous hands it round."""
+        """hp3d_comm_init on every rank: rank 0 draws the 128-byte id, the rendezvous hands it round.  Bounded by HP3D_RCCL_TIMEOUT."""
         if not self.comm_ready:
-            uid = self.rdzv.broadcast(self.engine.comm_unique_id() if self.rank == 0 else None, 0)
-            self.engine.comm_init(self.rank, self.world, uid)
+            msg = None
+            if self.rank == 0:
+                try:
+                    msg = self.engine.comm_unique_id()
+                except Exception as e:          # no RCCL on this box: the OTHER ranks are already waiting for the id -- tell them
+                    msg = 'hp3d_comm_unique_id failed on rank 0: %s: %s' % (type(e).__name__, e)
+            msg = self.rdzv.broadcast(msg, 0)
+            if isinstance(msg, str):
+                raise RuntimeError(msg)
+            self._with_deadline('hp3d_comm_init', self.engine.comm_init, self.rank, self.world, msg)
             self.comm_ready = True
 
     def sync_weights(self, weights=None, dtype=0, use_comm=None):
         """Rank 0 packs the weight dictionary; every other rank receives the packed device blob (and rank 0's nets mask
         and precision) by hp3d_bcast_weights -- no un-pickling or re-packing on the other ranks.  use_comm: None = only
         when world > 1; True forces the RCCL path at world size 1 as well (hardware smoke test of the exchange)."""
+        if self.tcp_only and self.world > 1:
+            # no communicator (use_tcp_only): rank 0's weight DICTIONARY travels over the rendezvous (tagged arrays, nothing un-pickled;
+            # 140 MB) and every rank packs its own copy -- still one source of truth, just not the packed blob over xGMI
+            weights = self.rdzv.broadcast(weights if self.rank == 0 else None, 0)
+            self.engine.load_weight_dict(weights)
+            self.engine.finalize_weights(dtype)
+            return
         if self.rank == 0:
             self.engine.load_weight_dict(weights)
             self.engine.finalize_weights(dtype)
         if use_comm or (use_comm is None and self.world > 1):
             self.comm_init()
-            self.engine.bcast_weights(0)
+            self._with_deadline('hp3d_bcast_weights', self.engine.bcast_weights, 0)      # (the first collective: where a half-built communicator would hang)
 
     sync_weights_native = sync_weights        # round-1 name
 
@@ -386,7 +430,7 @@ class ShardedPipeline(object):
         return np.concatenate([full[r, :s] for r, s in enumerate(sizes)], 0)
 
     def close(self):
-        if self.comm_ready:
+        if self.comm_ready and not self.comm_abandoned:
             self.engine.comm_destroy()
-            self.comm_ready = False
+        self.comm_ready = False
         self.rdzv.close()

@@ -59,11 +59,15 @@ class FakeEngine(object):
     def comm_init(self, rank, world, uid):
         if os.environ.get('HP3D_FAKE_RCCL_FAIL') == 'all' or os.environ.get('HP3D_FAKE_RCCL_FAIL') == str(rank):
             raise RuntimeError('ncclCommInitRank: unhandled system error (fake)')
+        if os.environ.get('HP3D_FAKE_RCCL_HANG') in ('all', str(rank)):
+            time.sleep(1e6)               # ncclCommInitRank that neither returns nor fails (seen once on a real box, round 5)
         assert uid == bytes(range(128)), "the rendezvous must deliver rank 0's id unchanged"
         self.rank, self.world = rank, world
         self._rec('comm_init %d/%d' % (rank, world))
 
     def bcast_weights(self, root=0):
+        if os.environ.get('HP3D_FAKE_RCCL_HANG') == 'bcast':
+            time.sleep(1e6)               # a communicator that came up and whose first collective never completes
         assert self.world is not None
         self._rec('bcast')
 

@@ -70,6 +70,32 @@ def test_bench_protocol_rccl_failure_degrades_to_tcp(fail):
         assert log.count('finalize') >= 1 and 'bcast' not in log.split('finalize')[-1]     # every rank ends on its own weights
 
 
+@pytest.mark.parametrize('hang', ['all', '1', 'bcast'])
+def test_bench_protocol_rccl_init_that_never_returns_has_a_deadline(hang):
+    """ncclCommInitRank (or the first broadcast) blocking forever -- on every rank, on one, or after the communicator came up: the set-up
+    calls run under HP3D_RCCL_TIMEOUT (hand3d_amd/dist.py), every rank agrees over the rendezvous, takes the TCP path and the JSON line
+    appears well inside a minute saying so (the driver's first 8-rank run must not be able to hang)."""
+    import time
+    world, port = 2, _free_port()
+    procs = []
+    t0 = time.time()
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   HP3D_FAKE_RCCL_HANG=hang, HP3D_RCCL_TIMEOUT='3')
+        procs.append(subprocess.Popen([sys.executable, HELPER, '--gpus', str(world), '--steps', '2', '--warmup', '1', '--batch', '2',
+                                       '--height', '16', '--width', '16'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert time.time() - t0 < 60
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    rec = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert rec['n_gpus'] == world and rec['value'] > 0
+    assert rec['config']['comm'].startswith('tcp-fallback (TimeoutError: rccl init timeout'), rec['config']['comm']
+    assert rec['config']['rccl_ranks'] == 0
+    for r in range(1, world):
+        assert outs[r][0].strip() == ''
+
+
 def test_bench_protocol_single_process_plain():
     env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     out = subprocess.run([sys.executable, HELPER, '--steps', '2', '--warmup', '0', '--batch', '2', '--height', '16', '--width', '16',
@@ -80,12 +106,13 @@ def test_bench_protocol_single_process_plain():
     assert 'comm_init' not in out.stderr            # no launcher -> no communicator
     # BASELINE.json's other configurations ride on the same line (N = 1, full workload, float32), each with its own timed region
     oc = rec['other_configs']
-    assert [c['config'] for c in oc] == ['C1', 'C2', 'C4-shard@240x320', 'C5-shard'], oc
+    assert [c['config'] for c in oc] == ['C1', 'C2', 'C4-shard@240x320', 'C3-split', 'C5-shard'], oc
     for c in oc:
         assert 'error' not in c, c
         assert c['images_per_s'] > 0 and c['ms_per_step'] > 0 and c['dominant_family'] == 'conv_wino'
         assert c['parity_spot'] is None              # --cpu-seconds 0: no oracle leg, no spot check
-    assert (oc[0]['batch'], oc[0]['height'], oc[0]['width']) == (1, 240, 320) and (oc[3]['batch'], oc[3]['height'], oc[3]['dtype']) == (128, 480, 'f16')
+    assert (oc[0]['batch'], oc[0]['height'], oc[0]['width']) == (1, 240, 320) and (oc[4]['batch'], oc[4]['height'], oc[4]['dtype']) == (128, 480, 'f16')
+    assert oc[3]['options'] == {'wino4_split': 'auto'} and (oc[3]['batch'], oc[3]['height']) == (32, 320)
     assert rec['config']['cpu_affinity'] is None    # pinning is for launched ranks only
 
 

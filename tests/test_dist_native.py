@@ -87,7 +87,9 @@ def _rccl_worker(rank, world, port, q):
         eng = Engine(0)                     # both ranks on the one GPU the box has
         sp = ShardedPipeline(eng, rank, world, Rendezvous(rank, world, '127.0.0.1', port, timeout=120))
         w = synth.make_weights() if rank == 0 else None
+        os.environ.setdefault('HP3D_RCCL_TIMEOUT', '90')     # the product's own deadline around ncclCommInitRank / the first broadcast
         sp.sync_weights(w)
+        q.put((rank, 'STAGE', 'synced', None))              # the communicator is up and has carried the weight blob
         img = synth.make_batch(40 + rank, 1, 240, 320)
         hs = synth.hand_sides(1)
         d_img, d_hs, d_c = eng.to_device(img), eng.to_device(hs), eng.dev_alloc(63 * 4)
@@ -114,29 +116,36 @@ def test_native_rccl_two_ranks_on_one_gpu(gpu_engine, synth_weights):
         p.start()
     import queue as _queue
     import time as _time
-    res, hung = [], False
-    deadline = _time.monotonic() + 180          # both ranks together (a fresh box pages the image in for up to two minutes)
+    res, synced, hung = [], set(), False
+    deadline = _time.monotonic() + 240          # both ranks together (a fresh box pages the image in for up to two minutes)
     try:
         while len(res) < 2:
             try:
-                res.append(q.get(timeout=max(1.0, deadline - _time.monotonic())))
+                m = q.get(timeout=max(1.0, deadline - _time.monotonic()))
             except _queue.Empty:
                 hung = True
                 break
+            if m[1] == 'STAGE':
+                synced.add(m[0])
+            else:
+                res.append(m)
     finally:
         for p in procs:
             p.join(5 if hung else 30)
             if p.is_alive():
                 p.kill()
+    # Expected failure ONLY while no rank got a working communicator: RCCL refusing two ranks on one device, or its set-up running into
+    # the product's deadline (hand3d_amd/dist.py, HP3D_RCCL_TIMEOUT).  A rank that hangs or fails AFTER the communicator carried the
+    # weights is a defect of the exchange and fails the test.
+    assert not (hung and synced), "ranks %s had a working communicator and the run still hung (%d of 2 answered)" % (sorted(synced), len(res))
     if hung:
-        # seen once in five rounds (a box on which ncclCommInitRank of two ranks on ONE device neither returned nor failed): the same
-        # limitation as the refusal below, reported the same way -- not a hang of the test session
-        pytest.xfail("this RCCL did not complete a 2-rank communicator on one device within 180 s (%d of 2 ranks answered)" % len(res))
+        pytest.xfail("this RCCL did not complete a 2-rank communicator on one device within the deadline (%d of 2 ranks answered)" % len(res))
     res.sort(key=lambda t: t[0])
     if any(r[1] != 'OK' for r in res):
         msg = '; '.join(str(r[2]) for r in res if r[1] != 'OK')
-        if 'uplicate' in msg or 'invalid usage' in msg.lower() or 'ncclCommInitRank' in msg:
-            pytest.xfail("this RCCL refuses two ranks on one device: %s" % msg)
+        setup = 'uplicate' in msg or 'invalid usage' in msg.lower() or 'ncclCommInitRank' in msg or 'rccl init timeout' in msg
+        if setup and not synced:
+            pytest.xfail("no 2-rank communicator on one device with this RCCL: %s" % msg[:400])
         raise AssertionError(msg)
     # rank 1 never saw the weight dictionary: its keypoints must equal what the session engine computes for its image
     from hand3d_amd import synth

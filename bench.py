@@ -250,7 +250,7 @@ def measure_config(eng, tag, what, call_site, workload, B, H, W, steps, warmup, 
         if workload == 'full':
             eng.infer_full_dev(B, H, W, int(d_img), int(d_hs), kpmap=int(d_kpmap), coord3d=int(d_coord), kp_hw=int(d_kphw))
         else:
-            eng.lib.hp3d_posenet2d_dev(eng.h, B, 256, 256, int(d_img), int(d_sm[0]), int(d_sm[1]), int(d_sm[2]))
+            eng._chk(eng.lib.hp3d_posenet2d_dev(eng.h, B, 256, 256, int(d_img), int(d_sm[0]), int(d_sm[1]), int(d_sm[2])))      # (a failing call must not be timed as a valid one)
         eng.sync()
 
     eng.set_profiling(0)
@@ -278,7 +278,8 @@ def measure_config(eng, tag, what, call_site, workload, B, H, W, steps, warmup, 
            "images_per_s": round(B * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps, "warmup": warmup,
            "alg_gflop_per_image": round((fl['total'] if workload == 'full' else fl['posenet']) / 1e9, 2),
            "dominant_family": dom, "executed_frac_of_dense_peak": roof["frac"], "executed_tflops": roof["achieved"],
-           "family_share_of_gpu_time": roof["share_of_gpu_time"], "profiled_ms_per_step": round(total_ms / psteps, 4)}
+           "family_share_of_gpu_time": roof["share_of_gpu_time"], "profiled_ms_per_step": round(total_ms / psteps, 4),
+           "profiled_pass_note": "events around every launch: the lifting towers and the first-touch pass run in ONE stream there (the timed region overlaps them)"}
     step()
     out = {}
     if workload == 'full':

@@ -211,7 +211,7 @@ void conv_wino7_kernel(const ConvParams p) {
     // packed U: [chunk][169 products][Cout/16][q 4][n 16][e 4]; the fragment of one (chunk, product) for a wave is 1 KB, lane-linear
     const int CO16 = p.Cout >> 4;
     const int nchunks = p.Cin / W7_CK;
-    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, (unsigned)(W7_SEQ * p.Cin) * (unsigned)p.Cout * 4u);
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, ((unsigned)(W7_SEQ * p.Cin) * (unsigned)p.Cout + (unsigned)(W7_RING * 256) * (unsigned)(p.Cout >> 4)) * 4u);      // (incl. the ring's slack: wino7_packed_floats)
     const int entry_stride_b = CO16 * 1024;
     const int wv_lane = lane * 16;
 
@@ -383,7 +383,9 @@ void conv_wino7_kernel(const ConvParams p) {
 // U = G g G^T per (block, channel, cout), G of F(4,4) over {0, 1, -1, 2, -2, 1/2, inf}, evaluated in double and rounded once; packed
 // [chunk = c / 16][product t (169: the non-zero (block, plane) pairs in kernel order)][Cout/16][q][n][e], channel c = 16 chunk + 4 q + e,
 // cout = 16 co16 + n (zero padded).  chan_map as in wino_pack_weights (the concat-buffer permutation of conv6_1 / conv7_1).
-size_t wino7_packed_floats(int cin_pad, int cout_pad) { return (size_t)W7_SEQ * cin_pad * cout_pad; }
+// (+ W7_RING entries of zeros: the weight ring keeps fetching W7_RING fragments past an item's last chunk through the SCALAR offset, which the
+//  raw-buffer range check does not cover -- for the layer's last chunk those reads must still land in memory this layer owns)
+size_t wino7_packed_floats(int cin_pad, int cout_pad) { return (size_t)W7_SEQ * cin_pad * cout_pad + (size_t)W7_RING * (cout_pad / 16) * 256; }
 
 void wino7_pack_weights(const float* g_hwio, int Cin, int Cout, int cin_pad, int cout_pad, const int* chan_map, float* dst) {
     const double G[7][4] = {{-1.0 / 2, 0, 0, 0},

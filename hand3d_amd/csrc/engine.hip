@@ -2591,6 +2591,9 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "conv_pw2_launches") { *value = ctx->conv_pw2_launches + (ctx->kid ? ctx->kid->conv_pw2_launches : 0); return 0; }
     if (k == "conv_wino7_split_launches") { *value = ctx->conv_wino7_split_launches + (ctx->kid ? ctx->kid->conv_wino7_split_launches : 0); return 0; }
     if (k == "conv_wino7_launches") { *value = ctx->conv_wino7_launches + (ctx->kid ? ctx->kid->conv_wino7_launches : 0); return 0; }
+#ifdef HP3D_EMU
+    if (k == "emu_soff_overreads") { *value = (long)hp3d_emu_soff_overreads; return 0; }     // interpreter only: 16-byte loads that left their buffer through the scalar offset
+#endif
     if (k == "conv_wino4s_launches") { *value = ctx->conv_wino4s_launches + (ctx->kid ? ctx->kid->conv_wino4s_launches : 0); return 0; }
     if (k == "conv_wino4s_tail_launches") { *value = ctx->conv_wino4s_tail_launches + (ctx->kid ? ctx->kid->conv_wino4s_tail_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }

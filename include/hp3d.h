@@ -246,6 +246,10 @@ int hp3d_pose3d(hp3d_ctx* ctx, int B, const float* scoremap32, const float* hand
  * hp3d_resize_bilinear tf.image.resize_images (TF1.3 legacy bilinear)         nets/ColorHandPose3DNetwork.py:97,128,166
  * hp3d_crop_and_resize crop_image_from_xy -> tf.image.crop_and_resize         utils/general.py:163-196
  * hp3d_mask_from_scoremap single_obj_scoremap + calc_center_bb + scale        utils/general.py:233-328, CHP3D.py:82-85
+ *                      SIZE LIMIT (the reference has none): the growth runs on bit-packed maps in ONE workgroup's LDS,
+ *                      3 * H * (ceil(W / 32) + 1) + 2 words <= 159 KB, e.g. 640x640 or 480x864 (since round 5 each row carries a
+ *                      zero guard word: 640x672, accepted before, is refused now); larger maps -> HP3D_ERR_ARG "too large".
+ *                      The whole-path entry points (hp3d_infer_full*, hp3d_infer_2d*) have the same limit on the input image.
  *                      -> mask [B,H,W], center [B,2], crop_size [B,1] (before *1.25), scale [B,1], seed int32 [B,2]
  * hp3d_fc              NetworkOps.fully_connected(_relu)                      utils/general.py:112-136
  * hp3d_argmax2d        detect_keypoints (per-channel first arg-max)           utils/general.py:331-344

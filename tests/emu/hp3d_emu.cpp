@@ -6,6 +6,7 @@
 
 EmuIdx hp3d_emu_threadIdx, hp3d_emu_blockIdx, hp3d_emu_blockDim, hp3d_emu_gridDim;
 float* hp3d_emu_smem = nullptr;
+unsigned long hp3d_emu_soff_overreads = 0;
 
 extern "C" void hp3d_emu_switch(void** save_sp, void* load_sp);
 asm(R"(

@@ -77,14 +77,22 @@ static inline void hp3d_emu_buffer_lds16(hp3d_rsrc_t r, float* lds_wave_base, un
 }
 #define HP3D_BUFFER_LDS16(rsrc, lds_wave_base, voff, soff, lane) \
     hp3d_emu_buffer_lds16((rsrc), (float*)(lds_wave_base), (unsigned)(voff) + (unsigned)(soff), (lane))
-static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned off) {
+// (hardware: the raw-buffer range check covers the VECTOR offset only -- a scalar offset that leaves the buffer reads whatever lies there.
+//  The interpreter does the same (with voff + soff checked together no test could see conv_wino7's ring running past its filters);
+//  one concession to a host process: a read that would leave the buffer through soff returns zeros instead of touching foreign memory, and is
+//  COUNTED -- hp3d_emu_soff_overreads, asserted 0 by tests/test_emu_kernels.py for buffers without slack)
+extern unsigned long hp3d_emu_soff_overreads;
+static inline f32x4 hp3d_emu_buffer_load16(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (off + 16u <= r.bytes) memcpy(&v, r.base + off, 16);
+    if (voff < r.bytes && voff + 16u <= r.bytes) {
+        if ((unsigned long)voff + soff + 16u <= r.bytes) memcpy(&v, r.base + voff + soff, 16);
+        else ++hp3d_emu_soff_overreads;
+    }
     return v;
 }
-#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
-#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
-#define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff) + (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16_NT(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff), (unsigned)(soff))
+#define HP3D_BUFFER_LOAD16_SC1(rsrc, voff, soff) hp3d_emu_buffer_load16((rsrc), (unsigned)(voff), (unsigned)(soff))
 static inline float hp3d_emu_buffer_load4(hp3d_rsrc_t r, unsigned voff, unsigned soff) {
     float v = 0.f;
     if (voff < r.bytes && voff + soff + 4u <= r.bytes) memcpy(&v, r.base + voff + soff, 4);

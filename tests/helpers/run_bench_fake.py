@@ -44,6 +44,9 @@ class FakeEngine(object):
         self.rank = self.world = None
         self.prof = 0
 
+    def _chk(self, rc):
+        assert rc == 0
+
     def _rec(self, what):
         FakeEngine.log.append(what)
 

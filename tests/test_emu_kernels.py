@@ -415,10 +415,14 @@ def test_winograd_f4x4_4x4_for_7x7_filters_on_interpreter(emu_engine, case):
         r = T.leaky_relu(r)
     emu_engine.set_option('wino7', '1')
     try:
-        n0 = emu_engine.counter('conv_wino7_launches')
+        n0, o0 = emu_engine.counter('conv_wino7_launches'), emu_engine.counter('emu_soff_overreads')
         y = emu_engine.conv2d(x, w, b, 1, bool(act), False)
         assert emu_engine.counter('conv_wino7_launches') == n0 + 1
         assert np.array_equal(y, emu_engine.conv2d(x, w, b, 1, bool(act), False)), "not deterministic"
+        #  the weight ring runs 13 fragments past an item's last chunk through the SCALAR offset, which the hardware's range check
+        # does not cover: the packed filters carry that much slack (wino7_packed_floats), so no 16-byte load leaves its buffer -- the
+        # per-op entry point allocates exactly the packed size, where the GPU could have faulted
+        assert emu_engine.counter('emu_soff_overreads') == o0, "a weight fetch left the filter buffer through the scalar offset"
     finally:
         emu_engine.set_option('wino7', 'auto')
     emu_engine.set_option('wino4', '1')

@@ -577,9 +577,11 @@ bool wino4_auto(int mode, bool posenet, int k, int cin_pad, int cout_pad, int Ho
     // A 3x3 launch's last, under-filled round runs as tail pieces (conv_wino4_tail_plan): q steps instead of a whole round of S4, + the
     // pieces' epilogues and the tail reduce launch (~2 units).  Round 5: the model above charged a whole round and sent B = 12 / 24 layers with
     // 1.2-1.5 rounds of items to the F(2x2,3x3) kernels (PoseNet2D conv4_2 at B = 24: 0.416 ms there against 0.352 for THIRTY-TWO images here).
-    // PoseNet2D only: HandSegNet's logits feed the mask threshold, where any change of kernel plan moves knife-edge pixels of the synthetic
-    // weights' noise maps (its plan per batch size is what the reference-code fixtures were checked against; see the comment above).
-    if (posenet && k == 3 && ks4 <= 1 && !two_streams) {
+    // (Rounds 4-5 applied this to PoseNet2D only: HandSegNet's logits feed the mask threshold, and the reference-code fixtures demanded bit-equal
+    // masks of noise maps whose knife-edge pixels move with ANY change of summation order -- a test fixture was choosing kernels.  Round 6: the
+    // fixtures carry the reference run's knife-edge pixels and the tests tell such a flip from a defect (tests/test_gpu_reference_fixtures.py:
+    // _mask_gate), so both trunks take the plan the model prices: +5-12 % at B = 8 ... 24, throughput monotonic in B again.)
+    if (k == 3 && ks4 <= 1 && !two_streams) {
         int tail_items = 0;
         const int q = conv_wino4_tail_plan(cin_pad, cout_pad, Ho, Wo, B, &tail_items);
         if (q > 0 && tail_items > 0) t4 = std::min(t4, c4 * (std::floor(items4 / cus) * S4 + q) + 2.0);
@@ -1360,6 +1362,8 @@ int auto_micro_batch(const hp3d_ctx* ctx, int B, int H, int W) {
     // 32 images fill every persistent grid of the path at the reference's sizes (exactly 256 conv_wino7 items, whole rounds of conv_wino4
     // items on most layers): chunks of 32 and a remainder beat balanced chunks there (round 5, 320x320: B = 48 as 24 + 24: 20.16 ms;
     // as 32 + 16: 11.99 + 6.70).  Where the 32-bit offsets allow fewer than 32 images per chunk the chunks stay balanced.
+    // (ADVICE r5 asked whether a small remainder -- B = 33 ... 40 -- should rather be balanced: measured in round 6, B = 40 at 320x320 as 32 + 8:
+    //  16.09 ms, as 20 + 20: 16.65 ms.  The full chunk keeps its rate; what helps such batches is the second stream, see infer_full_streams.)
     if (lim == 32) return 32;
     const int chunks = (B + lim - 1) / lim;
     return (B + chunks - 1) / chunks;
@@ -1431,11 +1435,16 @@ int infer_full_chunked(hp3d_ctx* ctx, int B, int H, int W, const float* image, c
                        float* coord3d, float* hand_mask, bool dev, const unsigned char* image_u8 = nullptr, int Hin = 0,
                        int Win = 0, int32_t* kp_crop = nullptr, double* kp_image = nullptr) {
     if (!ctx) return HP3D_ERR_ARG;
-    // "auto": two streams when each half still fills the persistent grids -- from 3 M input pixels per half.  Round 4 (tail pieces took the
+    // "auto": two streams when each half still fills the persistent grids -- from 2.4 M input pixels per half (3 M until round 6).  Round 4 (tail pieces took the
     // last-round quantisation out of the one-stream run; same box, float32, images/s one / two streams): B=32 320x320 2190 / 2115,
     // B=16 1975 / 1787, B=8 1666 / 1372, B=32 240x320 2454 / 2408 -- one stream; B=64 320x320 (two chunks of 32) 2195 / 2292, B=32 480x640
     // 989 / 1051, f16 B=128 480x640 3234 / 3321 -- two (profiles/r04_tuning_notes.md).
-    const int ns = ctx->nstreams >= 0 ? ctx->nstreams : ((long)(B / 2) * H * W >= 3000000L ? 2 : 1);
+    // Round 6: also between one and two full chunks (32 < B < 64 in float32 mode), where one stream runs a full chunk and then a latency-bound
+    // remainder: B = 40 at 320x320 2487 (32 + 8) -> 2616 images/s, B = 48 2591 -> 2622, 240x320 B = 48 2945 -> 3012 (profiles/r06_batch_sweep.txt).
+    // (From 40 images: B = 36 as 18 + 18 on two streams 2151, as 32 beside 4 2466, on one stream ~2430 -- halves below 20 images are too small.
+    //  A full chunk BESIDE the remainder instead of two halves loses from B = 40 on: 2502 / 2587 against 2609 / 2617 at B = 40 / 48.)
+    const bool between = !ctx->prec && ctx->micro_batch < 0 && B >= 40 && B < 64 && (long)H * W <= 320L * 320L;
+    const int ns = ctx->nstreams >= 0 ? ctx->nstreams : (((long)(B / 2) * H * W >= 2400000L || between) ? 2 : 1);        // (2.4 M: B = 64 at 240x320 3048 -> 3132)
     if (ns < 2 || B < 2 || ctx->profiling || ctx->use_graph || ctx->conv_naive || ctx->shared_weights || !hand_side ||
         (!image && !image_u8) || kid_sync_state(ctx) != 0)
         return infer_full_chunked1(ctx, B, H, W, image, hand_side, hand_scoremap, image_crop, scale_crop, center, kp_scoremap,

@@ -60,6 +60,19 @@ class Runner(object):
         return res
 
 
+KNIFE_EDGE = 4e-6          # |p_fg - 1/2| below which a det pixel is a coin toss of the float32 summation order (SURVEY section 7 "Hard parts")
+
+
+def knife_edge_pixels(hand_scoremap):
+    """(min |p_fg - 1/2| per image, [[image, row, col], ...] of the pixels below KNIFE_EDGE) of a [B,H,W,2] score map -- the hand mask is a
+    THRESHOLD of it (utils/general.py:240-245), so a kernel with another summation order may legitimately land such a pixel on the other side.
+    Stored with the fixtures so that the GPU tests can tell a knife-edge flip from a defect."""
+    s = hand_scoremap.astype(np.float64)
+    fg = 1.0 / (1.0 + np.exp(s[..., 0] - s[..., 1]))
+    m = np.abs(fg - 0.5)
+    return m.reshape(m.shape[0], -1).min(1), np.argwhere(m < KNIFE_EDGE).astype(np.int32).reshape(-1, 3)
+
+
 def main(argv=None, tf=None, eager=False, mods=None, set_empty_reduce=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--reference', default='/root/reference', help='checkout of lmb-freiburg/hand3d')
@@ -98,6 +111,7 @@ def main(argv=None, tf=None, eager=False, mods=None, set_empty_reduce=None):
         d[k + 'hand_side'] = hs[None]
         d[k + 'hand_scoremap_sub'] = hand_scoremap[0, ::8, ::8, :]     # = the 30x40 net output (legacy resize keeps sources)
         d[k + 'mask_packed'] = np.packbits(mask[0, :, :, 0].astype(np.uint8))
+        d[k + 'min_margin'], d[k + 'knife_iyx'] = knife_edge_pixels(hand_scoremap)
         d[k + 'center'], d[k + 'scale_crop'] = center, scale_crop
         d[k + 'image_crop_sub'] = image_crop[0, ::8, ::8, :]
         d[k + 'scoremap32'] = kp_scoremap[0, ::8, ::8, :]              # = PoseNet2D's last 32x32x21 map
@@ -127,6 +141,7 @@ def main(argv=None, tf=None, eager=False, mods=None, set_empty_reduce=None):
         np.savez_compressed(out('c4_b8_inference.npz'), seed0=np.load(inp('c4_seed0.npy')), shape=np.array(img.shape[1:3]), hand_side=sides,
                             hand_scoremap_sub=hand_scoremap[:, ::8, ::8, :],
                             mask_packed=np.stack([np.packbits(mask[i, :, :, 0].astype(np.uint8)) for i in range(len(img))]),
+                            min_margin=knife_edge_pixels(hand_scoremap)[0], knife_iyx=knife_edge_pixels(hand_scoremap)[1],
                             center=center, scale_crop=scale_crop, image_crop_sub=image_crop[:, ::8, ::8, :],
                             scoremap32=kp_scoremap[:, ::8, ::8, :], scoremap256_sum=kp_scoremap.sum(axis=(1, 2), dtype=np.float64),
                             keypoint_coord3d=coord3d, kp_crop=kps,

@@ -346,7 +346,7 @@ def other_configs_measure(eng, weights, a, device):
         img = np.concatenate([base] * (B // 16), 0)
         hs = synth.hand_sides(B)
         rec, _ = measure_config(eng16, 'C5-shard', "config 5's per-GPU shape: inference(), B=128, 480x640, f16 trunks (f32 accumulate, f32 heads / "
-                                "lifting / outputs)", 'run.py:44-46 at 480x640', 'full', B, H, W, 3, 1, 'f16', img, hs)
+                                "lifting / outputs)", 'run.py:44-46 at 480x640', 'full', B, H, W, 10, 2, 'f16', img, hs)
         rec["data"] = "16 distinct U(-0.5,0.5) frames (seeds 1000..1015) tiled to 128"
         rec["parity_spot"] = None
         fix = os.path.join(ROOT, 'tests', 'golden', 'c5_f16_480x640.npz')
@@ -618,15 +618,22 @@ def main():
     for _ in range(a.warmup):
         step()
     # ---- the timed region: profiling off (no per-launch events; hipGraph replay, if asked for, really replays) ----------
+    # The region of EXACTLY K steps (barrier + device sync on both sides, max over ranks) is run REPEATS times back to back and the MEDIAN
+    # region is the one reported (one 0.24 s sample cannot resolve the 0.5 % steps the tuning log works with;
+    # box-to-box spread is +-1.5 %); `value_min` / `value_max` carry the other two.
     eng.set_profiling(0)
-    rdzv.barrier()
-    eng.sync()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    eng.sync()
-    rdzv.barrier()
-    dt = rdzv.max(time.perf_counter() - t0)
+    REPEATS = 3
+    region_dt = []
+    for _ in range(REPEATS):
+        rdzv.barrier()
+        eng.sync()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            step()
+        eng.sync()
+        rdzv.barrier()
+        region_dt.append(rdzv.max(time.perf_counter() - t0))
+    dt = sorted(region_dt)[REPEATS // 2]
 
     # ---- separate profiled pass: HIP events around every launch on the engine stream, accumulated over K steps ----------
     eng.set_profiling(2)
@@ -702,6 +709,33 @@ def main():
                          "what": "pinned float32 frames on the host -> keypoint_coord3d [B,21,3] + 2-D keypoints [B,21,2] on the "
                                  "host per step; H2D of step n+1 overlapped with the kernels of step n; heat-maps stay on the device"}
             dev[1].free()
+            # SURVEY 8d's metric as written -- "wall-clock from host arrays in to keypoints out" -- on the entry point a caller with camera
+            # frames would use: UINT8 frames in pinned host memory -> hp3d_infer_full_kp_u8 (normalise on the device, the
+            # whole path, detect_keypoints / trafo_coords on the device) -> 3-D and 2-D keypoints on the host, blocking, a DIFFERENT batch
+            # every step (two alternating seeds), nothing overlapped by the caller.  4x less PCIe than the float32 path above.
+            u8 = [eng.pinned_empty((B, H, W, 3), np.uint8) for _ in range(2)]
+            for j, p8 in enumerate(u8):
+                p8[...] = np.clip(np.rint((synth.make_batch(5000 + 977 * j, B, H, W) + 0.5) * 255.0), 0, 255).astype(np.uint8)
+            c3 = np.empty((B, 21, 3), np.float32)
+            khw = np.empty((B, 21, 2), np.float64)
+
+            def step_u8(i):
+                eng._chk(eng.lib.hp3d_infer_full_kp_u8(eng.h, B, H, W, u8[i & 1].ctypes.data, H, W, hs_np.ctypes.data, None, None, None, None, None,
+                                                       c3.ctypes.data, None, None, khw.ctypes.data))
+            for i in range(2):
+                step_u8(i)
+            seen = []
+            tu = time.perf_counter()
+            for i in range(a.steps):
+                step_u8(i)
+                if i < 2:
+                    seen.append(c3.copy())
+            dtu = time.perf_counter() - tu
+            host_path["value_host_u8"] = round(B * a.steps / dtu, 2)
+            host_path["ms_per_step_host_u8"] = round(dtu / a.steps * 1e3, 3)
+            host_path["what_host_u8"] = ("uint8 frames in pinned host memory -> hp3d_infer_full_kp_u8 -> keypoint_coord3d [B,21,3] + 2-D keypoints "
+                                         "[B,21,2] on the host, blocking call per step, two different batches alternating (SURVEY 8d's metric as written)")
+            host_path["host_u8_batches_differ"] = bool(len(seen) == 2 and not np.array_equal(seen[0], seen[1]))
 
         # BASELINE.json's other configurations: GPU measurements first (see other_configs_measure), their oracle spot checks after the CPU leg
         oc = oc_keep = None
@@ -731,9 +765,14 @@ def main():
             "metric": "images/sec full pipeline (HandSegNet+crop+PoseNet2D+PosePrior/Viewpoint, RGB -> 21x3D kpts)"
                       if a.workload == 'full' else "images/sec PoseNet2D only (256x256 crops)",
             "value": round(n_img / dt, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value_min": round(n_img / max(region_dt), 2), "value_max": round(n_img / min(region_dt), 2), "timed_regions": REPEATS,
+            "value_host_u8": host_path.get("value_host_u8") if host_path else None,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic (seeded images, seeded fan-in-scaled weights)",
             "config": {"workload": workload_str,
+                       "headline": "`value` = inputs resident in HBM when the timed region starts, the MEDIAN of three K-step regions (value_min / "
+                                   "value_max: the other two); SURVEY 8d's metric as written -- host arrays in, keypoints out -- from uint8 frames is "
+                                   "`value_host_u8` (= host_path.value_host_u8), from float32 frames host_path.value",
                        "global_batch": B * world, "per_gpu_batch": B, "height": H, "width": W,
                        "parallelism": "batch-shard x%d, one process per GPU, no data-path collective; weights by hp3d_bcast_weights "
                                       "and a per-step keypoint all-gather (RCCL through the C ABI, TCP rendezvous; no torch)" % world,

@@ -29,8 +29,17 @@ class FakeBuf(object):
 
 
 class FakeLib(object):
+    calls = 0
+
     def hp3d_posenet2d_dev(self, *a):
         time.sleep(0.001)
+        return 0
+
+    def hp3d_infer_full_kp_u8(self, h, B, Hin, Win, img, H, W, hs, sm, crop, scale, center, kpmap, c3, mask, kpc, khw):
+        import ctypes
+        FakeLib.calls += 1
+        ctypes.memset(c3, FakeLib.calls & 1, 4)          # (two alternating batches give two different results)
+        time.sleep(0.002)
         return 0
 
 

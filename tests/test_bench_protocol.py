@@ -103,6 +103,9 @@ def test_bench_protocol_single_process_plain():
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec['n_gpus'] == 1 and rec['host_path'] is not None
+    # the headline is the median of three K-step regions; SURVEY 8d's host-arrays-in -> keypoints-out rate from uint8 frames rides beside it
+    assert rec['timed_regions'] == 3 and rec['value_min'] <= rec['value'] <= rec['value_max']
+    assert rec['value_host_u8'] == rec['host_path']['value_host_u8'] > 0 and rec['host_path']['host_u8_batches_differ'] is True
     assert 'comm_init' not in out.stderr            # no launcher -> no communicator
     # BASELINE.json's other configurations ride on the same line (N = 1, full workload, float32), each with its own timed region
     oc = rec['other_configs']

@@ -145,8 +145,24 @@ void conv_h16_kernel(const ConvParams p) {
     const int tap_stride_b = KB * CO32 * 1024;           // bytes between taps of the packed weights
 
     for (int item = blockIdx.x; item < nitems; item += (int)gridDim.x) {
-        int it = item;
-        const int cb = it % ncb; it /= ncb;
+        // XCD-affine item order (round 6, as conv_wino4's item_decode): workgroup ids go round-robin over the 8 XCDs, so with the cout block
+        // innermost the ncb items that read the SAME input patch landed on ncb different XCDs and the patch crossed the fabric once per cout
+        // block (counter traffic 1.65x the algorithmic bytes, profiles/r04_h16_counters.md).  Now consecutive items of one XCD are the cout
+        // blocks of one tile: the patch is fetched once per XCD and re-read from that XCD's L2.  (Whole groups of eight tiles in that
+        // order; the up to seven tiles left over behind them, still cout block innermost.)
+        int it, cb;
+        {
+            const int ntile = nitems / ncb, aff = (ntile >> 3) * 8 * ncb;
+            if (item < aff) {
+                const int xcd = item & 7, j = item >> 3, tq = j / ncb;
+                cb = j - tq * ncb;
+                it = tq * 8 + xcd;
+            } else {
+                const int q = item - aff, ti = q / ncb;
+                cb = q - ti * ncb;
+                it = (ntile & ~7) + ti;
+            }
+        }
         const int tx = it % tiles_x; it /= tiles_x;
         const int ty = it % tiles_y;
         [[maybe_unused]] const int b = it / tiles_y;          // (the host pass sees the buffer-descriptor stand-ins only)

@@ -59,6 +59,7 @@ struct ConvL {
     size_t ww4s_off = 0;   // the F(4x4,3x3) filters split into three bfloat16 pieces in conv_wino4s.hip's fragment order (3x3 trunk layers with Cin >= 128), 0 = none
     size_t ww7_off = 0;    // 7x7 layers: F(4x4,4x4) filters of the four 4x4-tap blocks in conv_wino7.hip's order [chunk][169][Cout/16][q][n][e], 0 = none
     size_t raw_off = 0;    // lifting nets only: [Cout/64][cin4][tap][64] for lift_fused.hip (one contiguous weight stream per wave), 0 = none
+    size_t hwio_off = 0;   // lifting nets, the last stride-2 layer of a tower (8x8 -> 4x4 map): the plain HWIO filter = the matrix of conv_s2_gemm_launch, 0 = none
     int cin4 = 0;
     int cin_pad16 = 0;     // f16 mode: input channels padded to 64 halves (one 128-B chunk)
     size_t w16_off = 0;    // offset into the f16 blob (halves); trunk nets only
@@ -115,6 +116,11 @@ struct Tables {
             l.cin4 = (cin + 15) / 16 * 16;          // four waves x whole channel quads
             l.raw_off = blob_floats;
             blob_floats += (size_t)9 * l.cin4 * ((cout + 63) / 64 * 64);
+        }
+        if (net == NET_VP && stride == 2 && k == 3 && cin >= 256) {          // (ViewpointNet/conv_vp_2_2: 47 -> 39 us; PosePrior's 128-channel twin measured slower this way)
+            blob_floats = (blob_floats + 3) / 4 * 4;
+            l.hwio_off = blob_floats;
+            blob_floats += (size_t)9 * cin * cout;
         }
         if (net == NET_SEG || net == NET_POSE) {     // half-precision copy for hp3d_finalize_weights(dtype=1)
             l.cin_pad16 = (l.mode == 1) ? 64 : (l.mode == 2) ? 192 : (cin + 63) / 64 * 64;
@@ -310,6 +316,10 @@ struct hp3d_ctx {
                                // 3x3 launches with Cin >= 128 that conv_wino4.hip would take), 1 wherever eligible (tests)
     long conv_wino4s_launches = 0;
     long conv_wino4s_tail_launches = 0;
+    int kp_up_side = 1;        // the heat-map up-sampling behind ViewpointNet on the child stream (1) or behind PosePrior on this one (0): option "kp_up_side"
+    int fc_tail = 1;           // the tail of a lifting tower (reduce of the first FC layer + the two small FC layers) as one launch (option "fc_tail")
+    int tiny_gemm = 1;         // the towers' last stride-2 layer (8x8 -> 4x4) as split-K GEMM over its output pixels (option "tiny_gemm")
+    long fc_tail_launches = 0, conv_s2_gemm_launches = 0;
     int w4_tail = 1;           // conv_wino4.hip: cut an under-filled last round of items into channel slices (option "wino4_tail")
     int use_pw2 = 1;           // conv_pw2.hip: the 1x1 head pairs (conv6_1 + conv6_2, conv5_1 + conv5_2, conv6_6 + conv6_7, conv7_6 + conv7_7) as one launch each
                                // (option "pw2": 0 never, 1 when the launch has a workgroup per CU, 2 = "force": whenever the shapes allow, tests)
@@ -473,7 +483,7 @@ int ensure_arena(hp3d_ctx* ctx, int B, int H, int W) {
         CHK(dev_realloc(ctx, &ctx->d_u, (size_t)B * 4));
         CHK(dev_realloc(ctx, &ctx->d_fc1, (size_t)B * 512));
         CHK(dev_realloc(ctx, &ctx->d_fc2, (size_t)B * 512));
-        CHK(dev_realloc(ctx, &ctx->d_fcpart, (size_t)B * 17 * 512 + (size_t)B * 33 * 256));
+        CHK(dev_realloc(ctx, &ctx->d_fcpart, std::max((size_t)B * 17 * 512 + (size_t)B * 33 * 256, (size_t)B * 16 * 18 * 256)));      // (FC slices; conv_s2_gemm: 18 slices x 16 B rows x 256)
         CHK(dev_realloc(ctx, &ctx->d_seed, (size_t)B * 2));
         CHK(dev_realloc(ctx, &ctx->d_keys, (size_t)B));
         ctx->capB = B;
@@ -616,6 +626,16 @@ int run_conv(hp3d_ctx* ctx, const ConvL& l, const float* in, int in_cs, int B, i
     const double flops = 2.0 * l.k * l.k * l.cin * l.cout * (double)Ho * Wo * B;
     const double bytes = (f16 ? 2.0 : 4.0) * ((double)B * H * W * l.cin + (double)l.k * l.k * l.cin * l.cout + l.cout +
                                 (double)B * (pool ? (Ho / 2) * (Wo / 2) : Ho * Wo) * l.cout);
+    if (l.hwio_off && ctx->tiny_gemm && !f16 && !pool && !ctx->conv_naive && l.stride == 2 && l.k == 3 && H == 8 && W == 8 && in_cs == l.cin && out_cs == l.cout) {
+        // the last stride-2 layer of a lifting tower: 16 output pixels per image -- a split-K GEMM over them (glue.hip: conv_s2_gemm_launch)
+        ProfScope ps(ctx, l.name, "conv_s2_gemm", flops, bytes);
+        conv_s2_gemm_launch(in, B, 8, l.cin, ctx->blob + l.hwio_off, ctx->blob + l.b_off, l.cout, l.relu, out, ctx->d_fcpart, ctx->stream);
+        ++ctx->conv_s2_gemm_launches;
+        HIPCHK(ctx, hipGetLastError());
+        if (Ho_out) *Ho_out = Ho;
+        if (Wo_out) *Wo_out = Wo;
+        return 0;
+    }
     int wino_ks = 1, wino2_ks = 1;
     const int old_nt = (ctx->use_wino && !f16 && l.ww_off) ? conv_wino_eligible(ctx->use_wino, l.k, l.stride, l.cin_pad, l.cout_pad, Ho, Wo, B, in_cs, out_cs, pool,
                                                                                  ctx->wino_splitk ? &wino_ks : nullptr) : 0;
@@ -1052,6 +1072,24 @@ int run_fc(hp3d_ctx* ctx, const FcL& l, const float* x, int B, int x_stride, flo
     return 0;
 }
 
+// the three FC layers of a tower as two launches (round 6): the K slices of the first, then its reduction + the two small layers (glue.hip: fc_tail_kernel)
+int run_fc_tail(hp3d_ctx* ctx, const FcL& l0, const FcL& l1, const FcL& l2, const float* x, int B, int x_stride, const float* hs, float* out, int out_stride) {
+    int ns;
+    {
+        ProfScope ps(ctx, l0.name, "fc_partial", 2.0 * l0.cin * l0.cout * B, 4.0 * ((double)l0.cin * l0.cout + (double)B * (l0.cin + l0.cout)));
+        ns = fc_partial_launch(x, B, l0.cin, x_stride, ctx->blob + l0.w_off, l0.cout, ctx->d_fcpart, ctx->stream, hs, l0.cin - 2);
+    }
+    {
+        ProfScope ps(ctx, l1.name + "+" + l2.name.substr(l2.name.find('/') + 1), "fc_tail", 2.0 * B * ((double)l1.cin * l1.cout + (double)l2.cin * l2.cout),
+                     4.0 * ((double)l1.cin * l1.cout + (double)l2.cin * l2.cout + (double)ns * B * l0.cout));
+        fc_tail_launch(ctx->d_fcpart, ns, B, l0.cout, ctx->blob + l0.b_off, l0.relu, ctx->blob + l1.w_off, ctx->blob + l1.b_off, l1.cout, l1.relu,
+                       ctx->blob + l2.w_off, ctx->blob + l2.b_off, l2.cout, l2.relu, out, out_stride, ctx->stream);
+    }
+    ++ctx->fc_tail_launches;
+    HIPCHK(ctx, hipGetLastError());
+    return 0;
+}
+
 // _inference_pose3d_can (nets/ColorHandPose3DNetwork.py:249-272; bottleneck: nets/PosePriorNetwork.py:115-116)
 int run_poseprior_can(hp3d_ctx* ctx, const float* sm32 /*[B,32,32,32]*/, const float* hs, int B, int bottleneck,
                       float* can) {
@@ -1070,6 +1108,8 @@ int run_poseprior_can(hp3d_ctx* ctx, const float* sm32 /*[B,32,32,32]*/, const f
     }
     // x: [B,4,4,128] contiguous == NHWC flatten (h,w,c)
     CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel0"), x, B, 2048, ctx->d_fc1, 512, hs));
+    // (round 6: ViewpointNet's tail runs as one launch, fc_tail_kernel; here that form measured SLOWER -- the 512 x 512 layer is a 1 MB weight
+    //  stream per workgroup (60 us), and with that layer kept on fc_partial the 512 -> 63 layer's K loop alone took 39 us: three plain FC layers stay)
     CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_rel1"), ctx->d_fc1, B, 512, ctx->d_fc2, 512));
     if (bottleneck) {
         CHK(run_fc(ctx, FL(ctx, "PosePrior/fc_bottleneck"), ctx->d_fc2, B, 512, ctx->d_fc1, 32));
@@ -1094,6 +1134,10 @@ int run_viewpoint(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, floa
         snprintf(nm, sizeof nm, "ViewpointNet/conv_vp_%d_2", i);
         CHK(run_conv(ctx, CL(ctx, nm), a, ch[i], B, h, w, b, ch[i], 0, &h, &w));
         x = b; cs = ch[i];   // next pair: b -> a -> b (no aliasing)
+    }
+    if (ctx->fc_tail && fc_tail_eligible(256, 128, 3)) {
+        CHK(run_fc_tail(ctx, FL(ctx, "ViewpointNet/fc_vp0"), FL(ctx, "ViewpointNet/fc_vp1"), FL(ctx, "ViewpointNet/fc_vp_u"), x, B, 4096, hs, u, 3));
+        return 0;
     }
     CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp0"), x, B, 4096, ctx->d_fc1, 256, hs));
     CHK(run_fc(ctx, FL(ctx, "ViewpointNet/fc_vp1"), ctx->d_fc1, B, 256, ctx->d_fc2, 128));
@@ -1178,7 +1222,7 @@ int ensure_side_tower(hp3d_ctx* k, int B) {
     if (B > k->sideB) {
         CHK(dev_realloc(k, &k->d_fc1, (size_t)B * 512));
         CHK(dev_realloc(k, &k->d_fc2, (size_t)B * 512));
-        CHK(dev_realloc(k, &k->d_fcpart, (size_t)B * 17 * 512 + (size_t)B * 33 * 256));
+        CHK(dev_realloc(k, &k->d_fcpart, std::max((size_t)B * 17 * 512 + (size_t)B * 33 * 256, (size_t)B * 16 * 18 * 256)));
         k->sideB = B;
     }
     return 0;
@@ -1186,7 +1230,11 @@ int ensure_side_tower(hp3d_ctx* k, int B) {
 
 // `beside` (may be null): work of the caller that depends on neither tower (the whole path's heat-map up-sampling and keypoint detection);
 // it runs on this context's stream behind PosePrior -- i.e. beside ViewpointNet when the towers run on two streams -- and before the epilogue.
-int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant, const std::function<int()>* beside = nullptr) {
+// `beside_side` (round 6, may be null): the part of that work that goes BEHIND ViewpointNet on the child stream instead when the towers run on two
+// streams -- since ViewpointNet's tower got shorter (fc_tail, conv_s2_gemm: 0.206 -> 0.179 ms) the parent stream (PosePrior 0.15 + up-sampling 0.037 +
+// keypoint detection 0.055) was the longer one; with the up-sampling on the child both are ~0.21 ms.  One stream: it simply runs after `beside`.
+int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int variant, const std::function<int(hipStream_t)>* beside = nullptr,
+               const std::function<int(hipStream_t)>* beside_side = nullptr) {
     const int do_rot = (variant == HP3D_VARIANT_PROPOSED);
     const bool fused = !ctx->conv_naive && (ctx->use_lift_fused == 1 || (ctx->use_lift_fused < 0 && B <= 4)) &&
                        (size_t)4 * B * 32 * 32 * 64 <= ctx->act_floats;
@@ -1214,8 +1262,9 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
             } join{ctx, k};
             const int rc = run_viewpoint(k, sm32, hs, B, ctx->d_u);
             if (rc != 0) { set_error(ctx, k->err.c_str()); return rc; }
+            if (beside_side && ctx->kp_up_side) { CHK((*beside_side)(k->stream)); beside_side = nullptr; }
             CHK(run_poseprior_can(ctx, sm32, hs, B, variant == HP3D_VARIANT_BOTTLENECK, ctx->d_can));
-            if (beside) { CHK((*beside)()); beside = nullptr; }
+            if (beside) { CHK((*beside)(ctx->stream)); beside = nullptr; }
             ++ctx->lift_overlap_calls;
         }
 #endif
@@ -1224,7 +1273,8 @@ int run_pose3d(hp3d_ctx* ctx, const float* sm32, const float* hs, int B, int var
             if (do_rot) CHK(run_viewpoint(ctx, sm32, hs, B, ctx->d_u));
         }
     }
-    if (beside) CHK((*beside)());
+    if (beside) CHK((*beside)(ctx->stream));
+    if (beside_side) CHK((*beside_side)(ctx->stream));
     if (variant == HP3D_VARIANT_LOCAL)     // bone_rel_trafo_inv (nets/PosePriorNetwork.py:70-75)
         bone_rel_inv_launch(ctx->d_can, B, ctx->d_coord, ctx->stream);
     else
@@ -1325,15 +1375,18 @@ int infer_full_impl(hp3d_ctx* ctx, int B, int H, int W, const float* image, cons
     CHK(run_posenet(ctx, ctx->d_crop, B, 256, 256, true));
     // (the heat-map up-sampling and the keypoint detection read PoseNet2D's last score map like the lifting towers do and depend on neither:
     //  they run beside ViewpointNet when the towers take two streams, option "lift_overlap")
-    const std::function<int()> kp_work = [&]() -> int {
+    const std::function<int(hipStream_t)> kp_up = [&](hipStream_t st) -> int {
         if (kp_scoremap) {
             ProfScope ps(ctx, "kp_upsample", "resize_bilinear", 0.0, 4.0 * B * (32 * 32 * 21 + 256 * 256 * 21));
-            resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, ctx->stream);
+            resize_bilinear_launch(ctx->d_sm[2], B, 32, 32, 21, 32, 256, 256, dev ? kp_scoremap : ctx->d_kpmap, st);
         }
+        return 0;
+    };
+    const std::function<int(hipStream_t)> kp_work = [&](hipStream_t) -> int {
         if (kp_crop || kp_image) CHK(run_kp_detect(ctx, B, kp_crop, kp_image, dev));
         return 0;
     };
-    CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED, &kp_work));
+    CHK(run_pose3d(ctx, ctx->d_sm[2], d_hs, B, HP3D_VARIANT_PROPOSED, &kp_work, &kp_up));
     CHK(copy_out(ctx, hand_scoremap, ctx->d_large, (size_t)B * H * W * 2, dev));
     CHK(copy_out(ctx, image_crop, ctx->d_crop, (size_t)B * 256 * 256 * 3, dev));
     CHK(copy_out(ctx, scale_crop, ctx->d_scale, (size_t)B, dev));
@@ -1424,7 +1477,7 @@ int kid_sync_state(hp3d_ctx* ctx) {
     hp3d_ctx* k = ctx->kid;
     k->blob = ctx->blob; k->blob16 = ctx->blob16; k->nets = ctx->nets; k->prec = ctx->prec;
     k->empty_fltmax = ctx->empty_fltmax; k->conv_naive = ctx->conv_naive; k->use_wino = ctx->use_wino;
-    k->use_first = ctx->use_first; k->first_touch = ctx->first_touch; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->use_wino4s = ctx->use_wino4s; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
+    k->use_first = ctx->use_first; k->first_touch = ctx->first_touch; k->first_balanced = ctx->first_balanced; k->use_wino2 = ctx->use_wino2; k->use_wino4 = ctx->use_wino4; k->fc_tail = ctx->fc_tail; k->tiny_gemm = ctx->tiny_gemm; k->use_wino4s = ctx->use_wino4s; k->w4_tail = ctx->w4_tail; k->use_wino7 = ctx->use_wino7; k->wino7_ksplit = ctx->wino7_ksplit; k->use_pw2 = ctx->use_pw2; k->use_lift_fused = ctx->use_lift_fused; k->use_h16 = ctx->use_h16; k->h16_k7k1 = ctx->h16_k7k1; k->fuse12 = ctx->fuse12; k->wino_splitk = ctx->wino_splitk; k->micro_batch = ctx->micro_batch;
     k->nstreams = 1; k->profiling = 0; k->use_graph = 0;
     return 0;
 #endif
@@ -1812,6 +1865,9 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
         return 0;
     }
     if (k == "wino4_split" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino4s = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
+    if (k == "fc_tail" && (v == "0" || v == "1")) { ctx->fc_tail = v == "1"; return 0; }
+    if (k == "kp_up_side" && (v == "0" || v == "1")) { ctx->kp_up_side = v == "1"; return 0; }
+    if (k == "tiny_gemm" && (v == "0" || v == "1")) { ctx->tiny_gemm = v == "1"; return 0; }
     if (k == "pw2" && (v == "0" || v == "1" || v == "force")) { ctx->use_pw2 = v == "0" ? 0 : v == "1" ? 1 : 2; return 0; }
     if (k == "wino7_ksplit") { ctx->wino7_ksplit = v == "auto" ? 0 : std::max(0, atoi(v.c_str())); return 0; }
     if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
@@ -1936,6 +1992,7 @@ int hp3d_finalize_weights(hp3d_ctx* ctx, int dtype) {
                     for (int c = 0; c < l.cin; ++c)
                         for (int co = 0; co < l.cout; ++co)
                             hp[l.raw_off + (((size_t)(co >> 6) * l.cin4 + c) * 9 + t) * 64 + (co & 63)] = w->data[((size_t)t * l.cin + c) * l.cout + co];
+            if (l.hwio_off) memcpy(hp + l.hwio_off, w->data.data(), sizeof(float) * (size_t)9 * l.cin * l.cout);
             if (l.ww_off) {      // U = G g G^T in the Winograd kernels' fragment orders
                 std::vector<int> cmap(l.cin_pad, -1);
                 for (int e = 0; e < l.cin_pad; ++e) {
@@ -2603,6 +2660,8 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
 #ifdef HP3D_EMU
     if (k == "emu_soff_overreads") { *value = (long)hp3d_emu_soff_overreads; return 0; }     // interpreter only: 16-byte loads that left their buffer through the scalar offset
 #endif
+    if (k == "fc_tail_launches") { *value = ctx->fc_tail_launches + (ctx->kid ? ctx->kid->fc_tail_launches : 0); return 0; }
+    if (k == "conv_s2_gemm_launches") { *value = ctx->conv_s2_gemm_launches + (ctx->kid ? ctx->kid->conv_s2_gemm_launches : 0); return 0; }
     if (k == "conv_wino4s_launches") { *value = ctx->conv_wino4s_launches + (ctx->kid ? ctx->kid->conv_wino4s_launches : 0); return 0; }
     if (k == "conv_wino4s_tail_launches") { *value = ctx->conv_wino4s_tail_launches + (ctx->kid ? ctx->kid->conv_wino4s_tail_launches : 0); return 0; }
     if (k == "conv_wino4_launches") { *value = ctx->conv_wino4_launches + (ctx->kid ? ctx->kid->conv_wino4_launches : 0); return 0; }

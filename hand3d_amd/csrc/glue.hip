@@ -592,8 +592,12 @@ constexpr int FC_KCH = 128, FC_BT = 32;
 // The thread's 32 weights are all requested BEFORE the first multiply-add (round 5: the loop used to load one weight per
 // iteration behind a data-dependent exit, 32 dependent HBM / L2 round trips per workgroup = 12-25 us per launch for a few
 // MFLOP; the sums are the same, in the same order: rows beyond Cin contribute fmaf(0, 0, acc) = acc).
+// conv_s (round 6): 0 = a plain matrix x; S > 0 = the rows are the OUTPUT PIXELS of a 3x3 / stride-2 / SAME convolution of an [n,S,S,conv_c] map (S even:
+// TensorFlow pads 0 before, 1 after), row = (image, oy, ox), column gk = (tap r * 3 + s) * conv_c + c -- i.e. the layer's HWIO filter IS the FC
+// matrix.  The lifting towers' last stride-2 layers (8x8 -> 4x4 maps: 512 output pixels at B = 32) run here: as implicit GEMMs on 8x8-pixel tiles
+// they were the slowest launches of the stage (ViewpointNet/conv_vp_2_2 47 us at 12.8 TFLOP/s).
 HP3D_KERNEL(256)
-void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float* x2, int F1, const float* w, int Cout, float* part) {
+void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float* x2, int F1, const float* w, int Cout, float* part, int conv_s, int conv_c) {
     __shared__ float xs[FC_KCH][FC_BT + 4];        // [k][b], pitch 36 floats (16-B aligned rows)
     __shared__ float red[4][FC_BT][64];
     const int o = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -610,7 +614,13 @@ void fc_partial_kernel(const float* x, int B, int Cin, int x_stride, const float
         const int b = i / FC_KCH, kk = i - b * FC_KCH;       // coalesced along k
         const int gb = b0 + b, gk = k0 + kk;
         float v = 0.f;
-        if (gb < B && gk < Cin) v = gk < F1 ? x[(size_t)gb * x_stride + gk] : x2[(size_t)gb * (Cin - F1) + (gk - F1)];
+        if (conv_s) {
+            if (gb < B && gk < Cin) {
+                const int so = conv_s >> 1, img = gb / (so * so), op = gb - img * so * so, oy = op / so, ox = op - oy * so;
+                const int tap = gk / conv_c, c = gk - tap * conv_c, iy = 2 * oy + tap / 3, ix = 2 * ox + tap % 3;
+                if (iy < conv_s && ix < conv_s) v = x[((size_t)(img * conv_s + iy) * conv_s + ix) * conv_c + c];
+            }
+        } else if (gb < B && gk < Cin) v = gk < F1 ? x[(size_t)gb * x_stride + gk] : x2[(size_t)gb * (Cin - F1) + (gk - F1)];
         xs[kk][b] = v;
     }
     __syncthreads();
@@ -660,6 +670,102 @@ void fc_reduce_kernel(const float* part, int nslices, int B, int Cout, const flo
         v += bias[o];
         if (act) v = leaky(v);
         out[(size_t)b * out_stride + o] = v;
+    }
+}
+
+// The tail of a lifting tower as ONE launch (round 6): the fixed-order reduction of the first FC layer's K slices (+ bias, leaky-ReLU), then the two small
+// FC layers behind it (PosePrior: 512 -> 512 -> 63, nets/ColorHandPose3DNetwork.py:264-270; ViewpointNet: 256 -> 128 -> 3, :299-307).  As
+// fc_partial + fc_reduce each, those were five launches of a few microseconds of work at the launch floor (18-20 us per layer); here a workgroup
+// takes FCT_G images through all three steps with the activations in LDS.  Layer 1: thread = (4 consecutive outputs, one K part), the parts added in
+// index order; layer 2: thread = (image, output).  Deterministic.
+constexpr int FCT_G = 2, FCT_MAXC = 512;
+HP3D_KERNEL(256)
+void fc_tail_kernel(const float* part0, int ns0, int B, int C0, const float* bias0, int act0, const float* w1, const float* b1, int C1, int act1,
+                    const float* w2, const float* b2, int C2, int act2, float* out, int out_stride) {
+    __shared__ __attribute__((aligned(16))) float h0[FCT_G][FCT_MAXC];
+    __shared__ __attribute__((aligned(16))) float h1[FCT_G][FCT_MAXC];
+    __shared__ __attribute__((aligned(16))) float red[8 * FCT_G * 128];          // [K part][image][C1] (C1 * parts = 1024)
+    const int tid = threadIdx.x, img0 = blockIdx.x * FCT_G;
+    // layer 0: the K slices in index order (what fc_reduce_kernel does), eight loads in flight
+    for (int i = tid; i < FCT_G * C0; i += 256) {
+        const int g = i / C0, o = i - g * C0, gb = img0 + g;
+        float v = 0.f;
+        if (gb < B) {
+            int sl = 0;
+            for (; sl + 8 <= ns0; sl += 8) {
+                float t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = part0[((size_t)(sl + u) * B + gb) * C0 + o];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v += t[u];
+            }
+            for (; sl < ns0; ++sl) v += part0[((size_t)sl * B + gb) * C0 + o];
+            v += bias0[o];
+            if (act0) v = leaky(v);
+        }
+        h0[g][o] = v;
+    }
+    __syncthreads();
+    // layer 1: C1 / 4 threads cover the outputs, 256 / (C1 / 4) K parts
+    {
+        const int no4 = C1 >> 2, kp = 256 / no4, o4 = (tid % no4) * 4, part = tid / no4;
+        const int klen = (C0 + kp - 1) / kp, k0 = part * klen, k1 = min(C0, k0 + klen);
+        f32x4 acc[FCT_G];
+#pragma unroll
+        for (int g = 0; g < FCT_G; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (part < kp) {
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {
+                f32x4 wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = *(const f32x4*)(w1 + (size_t)(k + u) * C1 + o4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int g = 0; g < FCT_G; ++g) {
+                        const float xv = h0[g][k + u];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[g][e] = fmaf(xv, wv[u][e], acc[g][e]);
+                    }
+            }
+            for (; k < k1; ++k) {
+                const f32x4 wv = *(const f32x4*)(w1 + (size_t)k * C1 + o4);
+#pragma unroll
+                for (int g = 0; g < FCT_G; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[g][e] = fmaf(h0[g][k], wv[e], acc[g][e]);
+            }
+#pragma unroll
+            for (int g = 0; g < FCT_G; ++g) *(f32x4*)&red[(part * FCT_G + g) * C1 + o4] = acc[g];
+        }
+        __syncthreads();
+        for (int i = tid; i < FCT_G * C1; i += 256) {
+            const int g = i / C1, o = i - g * C1;
+            float v = 0.f;
+            for (int pp = 0; pp < kp; ++pp) v += red[(pp * FCT_G + g) * C1 + o];
+            v += b1[o];
+            if (act1) v = leaky(v);
+            h1[g][o] = v;
+        }
+    }
+    __syncthreads();
+    // layer 2 (63 / 3 outputs): thread = (image, output), the K loop in index order
+    for (int i = tid; i < FCT_G * C2; i += 256) {
+        const int g = i / C2, o = i - g * C2, gb = img0 + g;
+        if (gb >= B) continue;
+        float v = 0.f;
+        int k = 0;
+        for (; k + 8 <= C1; k += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w2[(size_t)(k + u) * C2 + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v = fmaf(h1[g][k + u], wv[u], v);
+        }
+        for (; k < C1; ++k) v = fmaf(h1[g][k], w2[(size_t)k * C2 + o], v);
+        v += b2[o];
+        if (act2) v = leaky(v);
+        out[(size_t)gb * out_stride + o] = v;
     }
 }
 
@@ -922,9 +1028,28 @@ void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, con
                float* out, int out_stride, float* scratch, hipStream_t s, const float* x2, int F1) {
     const int ns = (Cin + FC_KCH - 1) / FC_KCH;
     HP3D_LAUNCH(fc_partial_kernel, dim3((Cout + 63) / 64, ns, (B + FC_BT - 1) / FC_BT), dim3(256), 0, s, x, B, Cin,
-                x_stride, x2, x2 ? F1 : Cin, w, Cout, scratch);
+                x_stride, x2, x2 ? F1 : Cin, w, Cout, scratch, 0, 0);
     HP3D_LAUNCH(fc_reduce_kernel, dim3(grid_for((long)B * Cout)), dim3(256), 0, s, (const float*)scratch, ns, B, Cout,
                 bias, act, out, out_stride);
+}
+// the K slices only (the reduction happens in the consumer: fc_tail_launch); returns the slice count
+int fc_partial_launch(const float* x, int B, int Cin, int x_stride, const float* w, int Cout, float* scratch, hipStream_t s, const float* x2, int F1) {
+    const int ns = (Cin + FC_KCH - 1) / FC_KCH;
+    HP3D_LAUNCH(fc_partial_kernel, dim3((Cout + 63) / 64, ns, (B + FC_BT - 1) / FC_BT), dim3(256), 0, s, x, B, Cin,
+                x_stride, x2, x2 ? F1 : Cin, w, Cout, scratch, 0, 0);
+    return ns;
+}
+int fc_tail_eligible(int C0, int C1, int C2) { return C0 <= FCT_MAXC && C2 >= 1 && C1 <= FCT_MAXC && C1 >= 4 && C1 % 4 == 0 && 256 % (C1 / 4) == 0 && (256 / (C1 / 4)) <= 8; }
+void fc_tail_launch(const float* part0, int ns0, int B, int C0, const float* bias0, int act0, const float* w1, const float* b1, int C1, int act1,
+                    const float* w2, const float* b2, int C2, int act2, float* out, int out_stride, hipStream_t s) {
+    HP3D_LAUNCH(fc_tail_kernel, dim3((B + FCT_G - 1) / FCT_G), dim3(256), 0, s, part0, ns0, B, C0, bias0, act0, w1, b1, C1, act1, w2, b2, C2, act2, out, out_stride);
+}
+// a 3x3 / stride-2 / SAME convolution of an [n,S,S,C] map (S even) as split-K GEMM over its S/2 x S/2 x n output pixels; w = the HWIO filter;
+// scratch: fc_scratch_floats(n * (S/2)^2, 9 C, Cout)
+void conv_s2_gemm_launch(const float* x, int n, int S, int C, const float* w_hwio, const float* bias, int Cout, int act, float* out, float* scratch, hipStream_t s) {
+    const int rows = n * (S / 2) * (S / 2), K = 9 * C, ns = (K + FC_KCH - 1) / FC_KCH;
+    HP3D_LAUNCH(fc_partial_kernel, dim3((Cout + 63) / 64, ns, (rows + FC_BT - 1) / FC_BT), dim3(256), 0, s, x, rows, K, 0, (const float*)nullptr, K, w_hwio, Cout, scratch, S, C);
+    HP3D_LAUNCH(fc_reduce_kernel, dim3(grid_for((long)rows * Cout)), dim3(256), 0, s, (const float*)scratch, ns, rows, Cout, bias, act, out, Cout);
 }
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B, float* rot,
                           float* coord_rel, int do_flip_rot, hipStream_t s) {

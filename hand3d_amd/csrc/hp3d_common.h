@@ -394,6 +394,13 @@ size_t fc_scratch_floats(int B, int Cin, int Cout);   // split-K partials [ceil(
 // x2 / F1: input columns F1 .. Cin-1 come from x2 (row stride Cin - F1): concat([flatten, hand_side]) without a copy; nullptr = plain
 void fc_launch(const float* x, int B, int Cin, int x_stride, const float* w, const float* bias, int Cout,
                int act, float* out, int out_stride, float* scratch, hipStream_t s, const float* x2 = nullptr, int F1 = 0);
+// round 6: the K slices of an FC layer only (the consumer reduces them); the tail of a lifting tower -- reduce of layer 0 + two small FC layers -- as one launch;
+// a 3x3 / stride-2 layer on an 8x8 map as split-K GEMM over its output pixels (w = the HWIO filter)
+int fc_partial_launch(const float* x, int B, int Cin, int x_stride, const float* w, int Cout, float* scratch, hipStream_t s, const float* x2 = nullptr, int F1 = 0);
+int fc_tail_eligible(int C0, int C1, int C2);
+void fc_tail_launch(const float* part0, int ns0, int B, int C0, const float* bias0, int act0, const float* w1, const float* b1, int C1, int act1,
+                    const float* w2, const float* b2, int C2, int act2, float* out, int out_stride, hipStream_t s);
+void conv_s2_gemm_launch(const float* x, int n, int S, int C, const float* w_hwio, const float* bias, int Cout, int act, float* out, float* scratch, hipStream_t s);
 // u = (ux,uy,uz) [B,3], coord_can [B,63], hand_side [B,2] -> rot [B,9], coord_rel [B,63]
 void lift_epilogue_launch(const float* u, const float* coord_can, const float* hand_side, int B,
                           float* rot, float* coord_rel, int do_flip_rot, hipStream_t s);

@@ -595,6 +595,7 @@ def test_lifting_towers_on_two_streams_equal_serial(gpu_engine, synth_weights):
     garbage in the rotation), growing and shrinking batches (the side tower's buffers follow), and within tolerance of the float64 oracle;
     the counter proves the two-stream form ran."""
     gpu_engine.load_weight_dict(synth_weights)
+    gpu_engine.finalize_weights()
     rng = np.random.default_rng(81)
     for B in (8, 32, 6):
         sm = np.maximum(rng.standard_normal((B, 32, 32, 21)).astype(np.float32), 0) * 0.3

@@ -30,6 +30,8 @@ def family(name):
         return 'conv_wino'
     if 'conv_wino2_kernel' in name:
         return 'conv_wino2'
+    if 'conv_wino4s_kernel' in name:      # (round 6: F(4x4,3x3) with split bf16x3 operands, option wino4_split; off by default)
+        return 'conv_wino4s'
     if 'conv_wino4_kernel' in name or 'conv_wino7_kernel' in name:      # (bench.py's family: Winograd with 4x4 output tiles, F(4x4,3x3) and the 7x7 layers' F(4x4,4x4))
         return 'conv_wino4'
     if 'conv_pw2_kernel' in name:
@@ -46,7 +48,7 @@ def family(name):
         return 'conv_first_touch'
     if 'wino4_tail_r' in name:
         return 'wino4_tail_reduce'
-    for k in ('conv_splitk_reduce', 'preprocess_u8', 'bone_rel_inv', 'fc_partial', 'fc_reduce', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
+    for k in ('conv_splitk_reduce', 'preprocess_u8', 'bone_rel_inv', 'fc_partial', 'fc_reduce', 'fc_tail', 'fc_kernel', 'im2col3x3', 'mask_grow', 'resize_bilinear', 'seg_upsample_softmax', 'crop_and_resize',
               'kp_detect', 'copy_channels', 'concat_handside', 'lift_epilogue', 'avgpool8', 'pad_channels'):
         if k in name:
             return k

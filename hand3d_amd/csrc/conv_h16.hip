@@ -416,6 +416,276 @@ void conv_h16_kernel(const ConvParams p) {
     }
 }
 
+// ---- the fused first block with conv1_2's FILTERS RESIDENT IN REGISTERS (round 6) ----------------------------------------------------------
+// conv_h16_kernel<1, true, 2, true> above measured 0.31 of the dense peak (matrix pipe busy 0.40, profiles/r06_h16_counters.md): with one cout
+// block per wave every A fragment read from LDS feeds ONE MFMA -- four waves x 1 KB per 32-cycle MFMA = the CU's whole 128 B/clk of LDS -- and
+// the filter ring asks the L1 for another 32 B/clk on top, while the layer's whole filter is 73.7 KB and the SAME for every one of the
+// 153,600 items of the config-5 shape.  Here:
+//   * one workgroup per CU, one wave per SIMD; a wave owns 4 output rows x 16 pixels x ALL 64 couts (2 row blocks x 2 cout blocks): an A
+//     fragment feeds two MFMAs (LDS at half its rate), and the wave's 72 filter fragments (36 K-steps x 2 cout blocks, 288 registers) are
+//     loaded ONCE per kernel -- no filter traffic at all inside the item loop;
+//   * the patch is double buffered and the NEXT item's patch (conv1_1 over the staged image window, the same MFMA form, operand order and
+//     rounding points as above) is built in slices between the K-steps of the current item; the window after that is fetched at the top of the
+//     loop and staged at its end: ONE workgroup barrier per item;
+//   * epilogue as above (bias, leaky-ReLU, halves, 2x2 max-pool through per-wave LDS slabs); a wave's slabs are the patch rows it builds
+//     itself, so no second barrier is needed.
+// Same results bit for bit as the form above (same products, same K order per accumulator).
+HP3D_KERNEL2(256, 1)
+void conv_h16_first_kernel(const ConvParams p) {
+    constexpr int FW = HPW + 2;                              // staged image window: 20 x 20 x 3 float32
+    constexpr int FWIN = FW * FW * 3;                        // 1200 floats; [FWIN] = 1.0 (bias rows), [FWIN + 1] = 0.0 (K tail)
+    constexpr int FWIN_PITCH = FWIN + 4;
+    constexpr int FWV = (FWIN + 255) / 256;                  // window floats per thread
+    constexpr int NBLK = (HPW * HPW + 31) / 32;              // 11 row blocks of 32 patch pixels
+    constexpr int OOR = (int)0x80000000;
+    constexpr int WRES_AGPR_STEPS = 32;                      // filter fragments of K-steps 0..31 live in the 256 AGPRs, the last four steps' in VGPRs
+    HP3D_DYN_SMEM(smem);
+    float* const fwin0 = smem + 2 * HPATCH_FLOATS;
+    float* const bias_l = fwin0 + 2 * FWIN_PITCH;            // conv1_2's 64 biases
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = HP3D_READFIRSTLANE(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int tiles_x = (p.Wo + HT - 1) / HT, tiles_y = (p.Ho + HT - 1) / HT;
+    const int nitems = p.B * tiles_y * tiles_x;
+    const int Hs = p.Ho >> 1, Ws = p.Wo >> 1;
+    // lane -> patch pixel of an A fragment: the conflict-free map of conv_h16_kernel (KS = 3)
+    const int pdy = li >> 4, pj = li & 15;
+    const int pdx = pdy == 0 ? (pj < 4 ? pj : pj < 12 ? pj + 4 : pj - 8) : (pj < 2 ? pj + 14 : pj < 4 ? pj - 2 : pj < 12 ? pj + 2 : pj - 10);
+    int abase[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) abase[mt] = ((((wave * 2 + mt) * 2 + pdy) * HPW + pdx) * HPITCH + lh * 4) * 4;
+    // conv1_1's filter matrix and operand slots, as in conv_h16_kernel<.., FUSE = true>
+    f32x4 bwh[2][2];
+    {
+        const int m = li, kh = lh;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float bias = p.bias1[nb * 32 + m], bias_hi = (float)(hp3d_f16)bias;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f16x8 hh;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * j + 8 * kh + i;
+                    const float wv = k < 27 ? p.wpk1[(((k >> 3) * 2 + nb) * 2 + ((k >> 2) & 1)) * 128 + m * 4 + (k & 3)] : 0.f;
+                    hh[i] = (hp3d_f16)(k < 27 ? wv : k == 27 ? bias_hi : k == 28 ? bias - bias_hi : 0.f);
+                }
+                bwh[nb][j] = __builtin_bit_cast(f32x4, hh);
+            }
+        }
+    }
+    int fkoff[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int k = 16 * (q >> 3) + 8 * lh + (q & 7);
+        const int r = k / 9, sx = (k / 3) % 3, c = k % 3;
+        fkoff[q] = k < 27 ? (r * FW + sx) * 3 + c : k < 29 ? FWIN : FWIN + 1;      // float index relative to the pixel's window corner / absolute
+    }
+    // conv1_2's filters: fragment (K-step s = 4 tap + ks, cout block nt) is the lane-linear 1-KB piece (2 s + nt) of the packed blob
+    const hp3d_rsrc_t wrsrc = HP3D_MAKE_RSRC(p.wpk, 9u * 64u * 32u * 4u);
+    f32x4 wres[36][2];
+#pragma unroll
+    for (int s = 0; s < 36; ++s)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) wres[s][nt] = HP3D_BUFFER_LOAD16(wrsrc, lane * 16, (s * 2 + nt) * 1024);
+    // this thread's floats of a window: f = tid + 256 v -> (row, col, channel)
+    int wrc[FWV];
+#pragma unroll
+    for (int v = 0; v < FWV; ++v) {
+        const int f = tid + v * 256;
+        const int row = f / (FW * 3), rem = f - row * (FW * 3), col = rem / 3, c = rem - col * 3;
+        wrc[v] = f < FWIN ? (row | (col << 8) | (c << 16)) : -1;
+    }
+    if (tid < 64) bias_l[tid] = p.bias[tid];
+    if (tid < 2) { fwin0[FWIN + tid] = tid ? 0.f : 1.f; fwin0[FWIN_PITCH + FWIN + tid] = tid ? 0.f : 1.f; }
+
+    struct Item { int b, oy0, ox0; };
+    auto decode = [&](int item) {
+        Item t;
+        if (item < nitems) {
+            const int tx = item % tiles_x, r = item / tiles_x;
+            t.b = r / tiles_y; t.oy0 = (r - t.b * tiles_y) * HT; t.ox0 = tx * HT;
+        } else { t.b = 0; t.oy0 = -(1 << 20); t.ox0 = -(1 << 20); }                 // past the end: every window pixel out of range (zeros)
+        return t;
+    };
+    char* const dump = (char*)(bias_l + 64) + tid * 8;       // where a lane without a real destination writes
+    float wreg[FWV];
+    auto win_fetch = [&](const Item& t) {
+        const hp3d_rsrc_t irsrc = HP3D_MAKE_RSRC(p.in + (size_t)t.b * p.H * p.W * 3, (unsigned)(p.H * p.W) * 12u);
+#pragma unroll
+        for (int v = 0; v < FWV; ++v) {
+            const int yy = t.oy0 - 2 + (wrc[v] & 255), xx = t.ox0 - 2 + ((wrc[v] >> 8) & 255), c = wrc[v] >> 16;
+            const bool ok = wrc[v] >= 0 && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            wreg[v] = HP3D_BUFFER_LOAD4(irsrc, ok ? ((yy * p.W + xx) * 3 + c) * 4 : OOR, 0);
+        }
+    };
+    auto win_commit = [&](int wb) {
+#pragma unroll
+        for (int v = 0; v < FWV; ++v) {
+            float* dst = (v + 1) * 256 <= FWIN || wrc[v] >= 0 ? fwin0 + wb * FWIN_PITCH + tid + v * 256 : (float*)dump;      // (no divergent branch)
+            *dst = wreg[v];
+        }
+    };
+    // the patch of item t = conv1_1 over its window, row block blk = wave + 4 j (j = 0..2; 11 blocks, so wave 3's third one is a dry run into a
+    // dump slot), cut into 11 slices of four pieces each; the item loop puts one piece in front of each of a K-step's four MFMAs:
+    //   slice 0: the 16 operand floats from the staged window; 1: rounding to halves; 2: the four MFMAs (K = 27 + 2 bias rows in two steps, two
+    //   cout halves); 3..10: (cout half nb, register group a): leaky-ReLU, rounding, zero outside the image, one 8-byte LDS write
+    int bpix[3], bwin[3], bpyx[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int pp = (wave + 4 * j) * 32 + li;
+        const int ppc = pp < HPW * HPW ? pp : 0;
+        const int py = ppc / HPW, px = ppc - py * HPW;
+        bpix[j] = pp < HPW * HPW ? pp * (HPITCH * 4) + 4 * lh * 2 : -1;     // byte offset inside a patch buffer (-1: dump slot)
+        bwin[j] = (py * FW + px) * 3;
+        bpyx[j] = pp < HPW * HPW ? (py | (px << 8)) : (255 | (255 << 8));   // (dry run: "outside the image")
+    }
+    float br[16];
+    f32x4 bah[2];
+    f32x16 bc[2];
+    unsigned bmask = 0, bword[2] = {0, 0};
+    auto build_piece = [&](const Item& t, int pb, int wb, int j, int slice, int pc) {
+        if (slice == 0) {
+            const float* fw = fwin0 + wb * FWIN_PITCH;
+            const float* wb0 = fw + bwin[j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = 4 * pc + i;
+                // slots with k >= 27 (the two bias rows' constant 1.0, the K tail's 0.0: step 1, lh = 1, slots 3..7) are absolute window indices
+                br[q] = (q >= 11) ? (lh ? fw[fkoff[q]] : wb0[fkoff[q]]) : wb0[fkoff[q]];
+            }
+        } else if (slice == 1) {
+            f16x4 hh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hh[i] = (hp3d_f16)br[4 * pc + i];
+            const f32x2 two = __builtin_bit_cast(f32x2, hh);
+            bah[pc >> 1][(pc & 1) * 2] = two[0]; bah[pc >> 1][(pc & 1) * 2 + 1] = two[1];
+        } else if (slice == 2) {
+            if (pc == 0) { HP3D_MFMA_OPERAND_FENCE(); HP3D_MFMA_32x32x16_F16_V_FIRST(bc[0], bwh[0][0], bah[0]); }
+            if (pc == 1) HP3D_MFMA_32x32x16_F16_V_FIRST(bc[1], bwh[1][0], bah[0]);
+            if (pc == 2) HP3D_MFMA_32x32x16_F16_V(bc[0], bwh[0][1], bah[1]);
+            if (pc == 3) HP3D_MFMA_32x32x16_F16_V(bc[1], bwh[1][1], bah[1]);
+        } else {
+            const int nb = (slice - 3) >> 2, a = (slice - 3) & 3;
+            if (slice == 3 && pc == 0) {
+                HP3D_MFMA_RESULT_FENCE2(bc[0], bc[1]);
+                const int gy = t.oy0 - 1 + (bpyx[j] & 255), gx = t.ox0 - 1 + (bpyx[j] >> 8);
+                bmask = ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) ? 0xffffffffu : 0u;
+            }
+            const float v = bc[nb][4 * a + pc];
+            br[pc] = hp3d_vmax(v, HP3D_LEAKY_SLOPE * v);
+            if (pc & 1) {                  // two halves per 32-bit word; outside the image (conv1_2's SAME padding pads conv1_1's OUTPUT): +0.0
+                f16x4 h2;
+                h2[0] = (hp3d_f16)br[pc - 1]; h2[1] = (hp3d_f16)br[pc]; h2[2] = h2[3] = (hp3d_f16)0.f;
+                bword[pc >> 1] = __builtin_bit_cast(u32x2, h2)[0] & bmask;
+            }
+            if (pc == 3) {
+                char* dst = bpix[j] >= 0 ? (char*)smem + pb * (HPATCH_FLOATS * 4) + bpix[j] + (32 * nb + 8 * a) * 2 : dump;
+                *(u32x2*)dst = u32x2{bword[0], bword[1]};
+            }
+        }
+    };
+
+    // prologue: windows of this workgroup's first two items, the first item's patch
+    int item = blockIdx.x;
+    Item cur_t = decode(item), nxt_t = decode(item + (int)gridDim.x);
+    win_fetch(cur_t); win_commit(0);
+    win_fetch(nxt_t); win_commit(1);
+    __syncthreads();
+    static_assert((NBLK + 3) / 4 == 3, "");
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int sl = 0; sl < 11; ++sl)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) build_piece(cur_t, 0, 0, j, sl, pc);
+    __syncthreads();
+
+    for (int n = 0; item < nitems; item += (int)gridDim.x, ++n) {
+        const int cur = n & 1;
+        const Item nn_t = decode(item + 2 * (int)gridDim.x);
+        f32x16 acc[2][2];
+        f32x4 fa[2][2];
+        f32x4 bias4[2][4];
+        auto a_fetch = [&](int set, int toff_b, int ks) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                fa[set][mt] = *(const f32x4*)((const char*)smem + cur * (HPATCH_FLOATS * 4) + abase[mt] + toff_b + ks * 32);
+        };
+        a_fetch(0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            HP3D_SCHED_BARRIER();
+            if (s == 0) win_fetch(nn_t);                                  // the window after next: global -> registers ...
+            if (s == 23) win_commit(cur);                                 // ... -> LDS (this item's window is spent: its patch is complete)
+            if (s == 35) {                                                // the epilogue's biases (the build's registers are free by now)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) bias4[nt][a] = *(const f32x4*)(bias_l + nt * 32 + a * 8 + lh * 4);
+            }
+            if (s + 1 < 36) {
+                const int t1 = (s + 1) >> 2, r1 = t1 / 3, c1 = t1 - r1 * 3;
+                a_fetch((s + 1) & 1, (r1 * HPW + c1) * HPITCH * 4, (s + 1) & 3);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mt = q >> 1, nt = q & 1;
+                HP3D_SCHED_BARRIER();
+                if (s % 12 < 11) build_piece(nxt_t, cur ^ 1, cur ^ 1, s / 12, s % 12, q);          // the next item's patch, block wave + 4 (s / 12)
+                HP3D_SCHED_BARRIER();
+                if (s == 0) HP3D_MFMA_32x32x16_F16_ACC_FIRST("a", acc[mt][nt], wres[s][nt], fa[s & 1][mt]);
+                else if (s < WRES_AGPR_STEPS) HP3D_MFMA_32x32x16_F16_ACC("a", acc[mt][nt], wres[s][nt], fa[s & 1][mt]);
+                else HP3D_MFMA_32x32x16_F16_ACC("v", acc[mt][nt], wres[s][nt], fa[s & 1][mt]);
+            }
+        }
+        HP3D_SCHED_BARRIER();
+        HP3D_MFMA_RESULT_FENCE4(acc[0][0], acc[0][1], acc[1][0], acc[1][1]);
+        __syncthreads();            // patch[cur] is spent (the slabs below reuse it), patch[cur ^ 1] and the staged window are complete
+
+        // ---- epilogue: accumulator (lane (li, lh), register 4 a + e) of (mt, nt) = pixel li of row block 2 wave + mt, cout 32 nt + 8 a + 4 lh + e.
+        //      This wave's two slabs = the patch rows it builds itself (blocks wave and wave + 4 of patch[cur]: 32 pixels x 144 B each).
+        const hp3d_rsrc_t orsrc = HP3D_MAKE_RSRC((hp3d_f16*)p.out + (size_t)cur_t.b * Hs * Ws * p.out_cs, (unsigned)(Hs * Ws) * (unsigned)p.out_cs * 2u);
+        constexpr int SPITCH = HPITCH * 4;                                   // 144 B per slab pixel: 64 couts + pad (conflict-free as above)
+        const int sp_w = pdy * 16 + pdx;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            char* sl = (char*)smem + cur * (HPATCH_FLOATS * 4) + (wave + 4 * mt) * (32 * SPITCH);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f16x4 h;
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {           // (pairs: v_pk_add_f32 / v_pk_mul_f32)
+                        const f32x2 x = f32x2{acc[mt][nt][a * 4 + 2 * e2], acc[mt][nt][a * 4 + 2 * e2 + 1]} + f32x2{bias4[nt][a][2 * e2], bias4[nt][a][2 * e2 + 1]};
+                        const f32x2 y = x * HP3D_LEAKY_SLOPE;
+                        h[2 * e2] = (hp3d_f16)hp3d_vmax(x[0], y[0]); h[2 * e2 + 1] = (hp3d_f16)hp3d_vmax(x[1], y[1]);
+                    }
+                    *(f16x4*)(sl + sp_w * SPITCH + lh * 8 + nt * 64 + a * 16) = h;
+                }
+        }
+        HP3D_WAVE_LDS_SYNC();
+        const int g = lane & 7, pp = lane >> 3;                              // 16-byte group of the pixel's 64 couts, pooled column 0..7
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const char* sl = (const char*)smem + cur * (HPATCH_FLOATS * 4) + (wave + 4 * mt) * (32 * SPITCH);
+            f16x8 m = *(const f16x8*)(sl + (2 * pp) * SPITCH + g * 16);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const f16x8 o = *(const f16x8*)(sl + ((w >> 1) * 16 + 2 * pp + (w & 1)) * SPITCH + g * 16);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = m[e] > o[e] ? m[e] : o[e];
+            }
+            const int yp = (cur_t.oy0 >> 1) + wave * 2 + mt, xp = (cur_t.ox0 >> 1) + pp;
+            const int off = (yp < Hs && xp < Ws) ? (yp * Ws + xp) * (p.out_cs * 2) + g * 16 : OOR;
+            HP3D_BUFFER_STORE16(orsrc, __builtin_bit_cast(f32x4, m), off, 0);
+        }
+        HP3D_WAVE_LDS_SYNC();        // (the interpreter's fibers: the slab reads end before this wave's next build slices overwrite them)
+        cur_t = nxt_t; nxt_t = nn_t;
+    }
+}
+
 template <int NT, bool POOL, int KS = 3>
 void h16_launch_t(const ConvParams& p, hipStream_t s) {
     static bool attr_done[64] = {};
@@ -464,12 +734,28 @@ void h16_fused12_launch_t(const ConvParams& p, hipStream_t s) {
     HP3D_LAUNCH(k, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SMEM, s, p);
 }
 
+// the filter-resident form: one workgroup per CU walking items with a two-deep software pipeline -- worth it from a few items per workgroup on
+void h16_first_resident_launch(const ConvParams& p, hipStream_t s) {
+    static bool attr_done[64] = {};
+    constexpr int SMEM = 2 * HPATCH_FLOATS * 4 + 2 * ((HPW + 2) * (HPW + 2) * 3 + 4) * 4 + 64 * 4 + 256 * 8;     // patches, windows, biases, dump slots
+    static_assert(SMEM <= 160 * 1024, "LDS per CU");
+    if (hp3d_first_use_on_device(attr_done))
+        (void)hipFuncSetAttribute((const void*)conv_h16_first_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    const long items = (long)p.B * ((p.Ho + HT - 1) / HT) * ((p.Wo + HT - 1) / HT);
+    const int slots = hp3d_num_cus();
+    HP3D_LAUNCH(conv_h16_first_kernel, dim3((unsigned)(items < slots ? items : slots)), dim3(256), SMEM, s, p);
+}
+
 }  // namespace
 
+// p.first_form: 0 = by size (the filter-resident form from four items per CU on), 1 = the two-workgroups-per-CU form, 2 = the filter-resident form.
+// Returns the form that ran (1 / 2) or -1.
 int conv_h16_fused12_launch(const ConvParams& p, hipStream_t s) {
-    if (p.Cout != 64 || p.Cin != 32 || !p.wpk1 || !p.bias1 || ((p.Ho | p.Wo) & 1) || !p.act) return -1;
-    h16_fused12_launch_t(p, s);
-    return 0;
+    if (p.Cout != 64 || p.Cin != 32 || !p.wpk1 || !p.bias1 || ((p.Ho | p.Wo) & 1) || !p.act || p.out_cs != 64 || p.cout_store != 64) return -1;
+    const long items = (long)p.B * ((p.Ho + HT - 1) / HT) * ((p.Wo + HT - 1) / HT);
+    const bool resident = p.first_form == 2 || (p.first_form == 0 && items >= 4L * hp3d_num_cus());
+    if (resident) h16_first_resident_launch(p, s); else h16_fused12_launch_t(p, s);
+    return resident ? 2 : 1;
 }
 
 // 3x3 / stride 1, half-precision operands and output (not the float32 score-map heads), Cin a multiple of 64 halves,

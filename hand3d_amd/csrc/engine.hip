@@ -308,7 +308,9 @@ struct hp3d_ctx {
     int use_wino2 = -1;        // conv_wino2.hip (two workgroups per CU): -1 auto (short reductions, under-filled launches), 0 never, 1 wherever eligible (option "wino2")
     int use_graph = 0;
     long graph_captures = 0, graph_replays = 0;     // hp3d_get_counter: did the hipGraph path really run?
-    int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12")
+    int fuse12 = 1;            // half-precision trunks: conv1_1 computed inside conv1_2's patch stage (option "f16_fuse12": 0 | 1 = form by size |
+                               // 2 = "ring": two workgroups per CU, filter ring | 3 = "resident": one per CU, conv1_2's filters in registers)
+    long conv_h16_first_resident_launches = 0;
     long conv_h16_launches = 0;                     // hp3d_get_counter: layers that went to conv_h16.hip (the child context counts its own)
     int use_wino4 = -2;        // conv_wino4.hip (Winograd F(4x4,3x3)), option "wino4": -2 auto (both trunks by cost model), -1 "pose" (PoseNet2D only, by cost
                                // model), 0 never, 1 wherever eligible (tests)
@@ -954,7 +956,10 @@ int run_fused12(hp3d_ctx* ctx, const ConvL& l1, const ConvL& l2, const float* im
     const double bytes = px * 12 + 2.0 * (9 * 3 * 64 + 9 * 64 * 64) + 2.0 * px / 4 * 64;
     ProfScope ps(ctx, l2.name, "conv_h16_fused_c1_1+c1_2_pool", flops, bytes);
     ++ctx->conv_h16_launches;
-    if (conv_h16_fused12_launch(p, ctx->stream)) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 fused launch failed for %s", l2.name.c_str());
+    p.first_form = ctx->fuse12 == 2 ? 1 : ctx->fuse12 == 3 ? 2 : 0;
+    const int form = conv_h16_fused12_launch(p, ctx->stream);
+    if (form < 0) HP3D_FAIL(ctx, HP3D_ERR_UNSUPPORTED, "conv_h16 fused launch failed for %s", l2.name.c_str());
+    if (form == 2) ++ctx->conv_h16_first_resident_launches;
     *oh = H / 2; *ow = W / 2;
     return 1;
 }
@@ -1872,7 +1877,9 @@ int hp3d_set_option(hp3d_ctx* ctx, const char* key, const char* value) {
     if (k == "wino7_ksplit") { ctx->wino7_ksplit = v == "auto" ? 0 : std::max(0, atoi(v.c_str())); return 0; }
     if (k == "wino7" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino7 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
     if (k == "wino2" && (v == "0" || v == "1" || v == "auto")) { ctx->use_wino2 = v == "auto" ? -1 : v == "1" ? 1 : 0; return 0; }
-    if (k == "f16_fuse12" && (v == "0" || v == "1")) { ctx->fuse12 = v == "1"; ++ctx->graph_epoch; return 0; }
+    if (k == "f16_fuse12" && (v == "0" || v == "1" || v == "ring" || v == "resident")) {
+        ctx->fuse12 = v == "0" ? 0 : v == "1" ? 1 : v == "ring" ? 2 : 3; ++ctx->graph_epoch; return 0;
+    }
     if (k == "f16_k7k1" && (v == "0" || v == "1")) { ctx->h16_k7k1 = v == "1"; return 0; }
     if (k == "f16_impl" && (v == "h16" || v == "mfma" || v == "h16_force")) { ctx->use_h16 = v == "mfma" ? 0 : v == "h16" ? 1 : 2; return 0; }
     if (k == "streams" && (v == "1" || v == "2" || v == "auto")) { ctx->nstreams = v == "auto" ? -1 : v == "2" ? 2 : 1; return 0; }
@@ -2649,6 +2656,7 @@ int hp3d_get_counter(hp3d_ctx* ctx, const char* name, long long* value) {
     if (k == "graph_captures") { *value = ctx->graph_captures; return 0; }
     if (k == "graph_replays") { *value = ctx->graph_replays; return 0; }
     if (k == "conv_h16_launches") { *value = ctx->conv_h16_launches; return 0; }
+    if (k == "conv_h16_first_resident_launches") { *value = ctx->conv_h16_first_resident_launches; return 0; }
     if (k == "first_touch_launches") { *value = ctx->first_touch_launches + (ctx->kid ? ctx->kid->first_touch_launches : 0); return 0; }
     if (k == "conv_first_launches") { *value = ctx->conv_first_launches + (ctx->kid ? ctx->kid->conv_first_launches : 0); return 0; }
     if (k == "lift_overlap_calls") { *value = ctx->lift_overlap_calls; return 0; }

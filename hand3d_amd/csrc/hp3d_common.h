@@ -18,6 +18,7 @@ typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((vector_size(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 // two float32 -> two bfloat16 (round to nearest even), `lo` in bits 0..15
 static __device__ __forceinline__ unsigned hp3d_cvt_pk_bf16(float lo, float hi) {
     unsigned r;
@@ -35,6 +36,25 @@ static __device__ __forceinline__ unsigned hp3d_cvt_pk_bf16(float lo, float hi) 
 // 16-B fragments (held as f32x4) reinterpreted as 8 halves: lane l carries k = 8*(l>>5) .. 8*(l>>5)+7
 #define HP3D_MFMA_32x32x16_F16(a, b, c) \
     __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, (a)), __builtin_bit_cast(f16x8, (b)), (c), 0, 0, 0)
+// the same instruction as a statement with the accumulator in VGPRs (the epilogue's VALU reads it there) and the A operand (REG_A = "a": an AGPR
+// tuple, "v": a VGPR tuple) read where it lives: conv_h16_first_kernel keeps 72 filter fragments = 288 registers resident, 256 of them in
+// AGPRs, and hipcc would otherwise copy every AGPR-parked fragment to VGPRs in front of its MFMA (434 v_accvgpr_read per item).  Operands come from registers
+// loaded once per kernel (A) and from LDS (B: the compiler's s_waitcnt in front of the statement covers it); _FIRST starts the chain from
+// the inline constant 0 (no register clearing in front of an MFMA hipcc cannot see into).  HP3D_MFMA_RESULT_FENCE*: a VALU read of an MFMA result
+// needs up to 19 wait states behind a 16-pass MFMA, and hipcc does not count them across an asm statement.
+#define HP3D_MFMA_32x32x16_F16_ACC(REG_A, acc, a, b) \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : REG_A(a), "v"(b))
+#define HP3D_MFMA_32x32x16_F16_ACC_FIRST(REG_A, acc, a, b) \
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : REG_A(a), "v"(b))
+// max of two floats neither of which is a signalling NaN (matrix-core sums): fmaxf() costs a canonicalising v_max_f32 x, x in front
+static __device__ __forceinline__ float hp3d_vmax(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+// (the accumulators pass THROUGH the statement: without the data dependence hipcc moved the first VALU read in front of the s_nop pair)
+#define HP3D_MFMA_RESULT_FENCE2(r0, r1) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(r0), "+v"(r1))
+#define HP3D_MFMA_RESULT_FENCE4(r0, r1, r2, r3) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3))
+// ... both operands in VGPRs (conv1_1 inside conv_h16_first_kernel; hipcc's own choice for that chain was AGPR accumulators + 32 v_accvgpr_read,
+// and it evicted resident filter fragments to make room)
+#define HP3D_MFMA_32x32x16_F16_V(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+#define HP3D_MFMA_32x32x16_F16_V_FIRST(acc, a, b) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(acc) : "v"(a), "v"(b))
 // four dependent v_mfma_f32_32x32x2_f32 on one accumulator tuple (an accumulate chain), skipped as a whole when the wave-uniform
 // `skip` is non-zero.  The branch lives INSIDE the statement so that the compiler sees one opaque read-modify-write of the
 // accumulator: a source-level `if` around 16 MFMAs makes hipcc merge two versions of a 16-register tuple at the join and it
@@ -291,6 +311,7 @@ struct ConvParams {
     // packed weights (mode 1, as conv_first reads them) and bias; nullptr otherwise
     const float* wpk1 = nullptr;
     const float* bias1 = nullptr;
+    int first_form = 0;       // 0 = by size, 1 = two workgroups per CU with a filter ring, 2 = one per CU with conv1_2's filters resident in registers
     // conv_wino4.hip tail pieces (set by conv_wino4_launch from `partial` / `partial_cap`): the last, under-filled round of items
     // (tail_items of them) is shared out in runs of tail_q channel steps per workgroup, raw sums to `partial`; 0 = off
     int tail_items = 0, tail_q = 0;

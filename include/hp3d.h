@@ -145,9 +145,12 @@ int hp3d_sync(hp3d_ctx* ctx);
  *          "f16_k7k1"     = "1" (default) | "0": with "f16_impl" on conv_h16.hip, PoseNet2D's 7x7 score-map stages and the 1x1 layers with
  *                            >= 64 couts also run on it (single-buffer forms, patch of (16 + k - 1)^2 pixels) | on the general kernel.
  *                            Same MFMA and packed weights: results agree to accumulation order;
- *          "f16_fuse12"   = "1" (default) | "0": with half-precision trunks and the layer on conv_h16.hip, conv1_1 is computed
+ *          "f16_fuse12"   = "1" (default) | "0" | "ring" | "resident": with half-precision trunks and the layer on conv_h16.hip, conv1_1 is computed
  *                            inside conv1_2's patch stage (one launch for conv1_1 + conv1_2 + max-pool; conv1_1's activation
- *                            never reaches HBM).  Bit-identical to the two-launch form;
+ *                            never reaches HBM).  Bit-identical to the two-launch form.  Two forms of that launch (round 6): "ring" = two
+ *                            workgroups per CU, conv1_2's filters through a register ring; "resident" = one workgroup per CU with the
+ *                            filters resident in registers and the next tile's patch built between the MFMAs of the current one
+ *                            (conv_h16_first_kernel); "1" takes "resident" from four tiles per CU on, else "ring";
  *          "wino4_split"  = "0" (default) | "auto" | "1" (round 6): the 3x3 / stride-1 trunk layers with Cin >= 128 whose launch fills the chip run
  *                            Winograd F(4x4,3x3) with the plane products on v_mfma_f32_16x16x32_bf16 over THREE bfloat16 pieces per operand (six
  *                            products, float32 accumulate: conv_wino4s.hip) | never | wherever the shape allows (tests).  Float32 in and out; per

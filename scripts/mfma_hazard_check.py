@@ -41,6 +41,52 @@ def check(lines, need=2):
     return bad
 
 
+MFMA_PASSES = (('32x32x16', 8), ('16x16x32', 4), ('32x32x2_f32', 16), ('32x32x2f32', 16), ('16x16x4_f32', 8), ('16x16x4f32', 8), ('32x32x8', 16), ('16x16x16', 8))
+
+
+def check_result(lines, extra=4):
+    """The other direction (round 6, conv_h16_first_kernel's asm MFMAs with VGPR accumulators): a VALU / LDS / VMEM instruction that READS a VGPR an
+    MFMA wrote needs passes + `extra` wait states behind that MFMA (hipcc counts them for its own MFMAs -- its `s_nop` in front of the first
+    v_accvgpr_read / VALU read of a result -- and cannot for MFMAs inside asm statements; another MFMA reading the result as SrcC is interlocked
+    by hardware).  Returns (index of the MFMA, wait states found, needed, the reader, the MFMA)."""
+    bad = []
+    for i, l in enumerate(lines):
+        if not l.startswith('v_mfma'):
+            continue
+        ops = [t.strip() for t in l.split(None, 1)[1].split(',')]
+        dst = regs(ops[0])
+        if not dst:
+            continue                     # accumulator in AGPRs: read back by v_accvgpr_read, which the compiler schedules itself
+        passes = next((n for key, n in MFMA_PASSES if key in l.split()[0]), 16)
+        need = passes + extra
+        states = 0
+        for k in range(i + 1, len(lines)):
+            if states >= need:
+                break
+            p = lines[k]
+            m = re.match(r's_nop\s+(\d+)', p)
+            if m:
+                states += int(m.group(1)) + 1
+                continue
+            if p.startswith(('s_barrier', 's_cbranch', 's_branch', 's_endpgm')):
+                break                    # (control flow: not followed; a barrier is not counted on either)
+            toks = p.split(None, 1)
+            if len(toks) == 2 and not p.startswith('v_mfma') and p[0] in 'vdbg':     # VALU, ds_*, buffer_*, global_*
+                srcs = [t.strip() for t in toks[1].split(',')]
+                if p.startswith('v_') or '_read' in toks[0] or '_load' in toks[0]:
+                    srcs = srcs[1:]                                                 # first operand of a VALU instruction / a load is its destination
+                read = set()
+                for t in srcs:
+                    read |= regs(t.split()[0]) if t else set()
+                if read & dst:
+                    bad.append((i, states, need, p, l))
+                    break
+            if p.startswith('v_mfma') and regs(p.split(None, 1)[1].split(',')[0].strip()) & dst:
+                break                    # overwritten by a later MFMA: that one's own check takes over
+            states += 1
+    return bad
+
+
 def kernels_of(txt):
     out = {}
     cur = None

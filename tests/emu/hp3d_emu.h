@@ -23,6 +23,7 @@ typedef _Float16 hp3d_f16;
 typedef _Float16 f16x8 __attribute__((vector_size(16)));
 typedef _Float16 f16x4 __attribute__((vector_size(8)));
 typedef unsigned u32x4 __attribute__((vector_size(16)));
+typedef unsigned u32x2 __attribute__((vector_size(8)));
 // two float32 -> two bfloat16, round to nearest even (v_cvt_pk_bf16_f32); `lo` in bits 0..15
 static inline unsigned hp3d_emu_bf16_rne(float f) {
     unsigned u; memcpy(&u, &f, 4);
@@ -146,6 +147,17 @@ f32x4 hp3d_emu_mfma_16x16x4(float a, float b, f32x4 c);
 #define HP3D_MFMA_16x16x4(a, b, c) hp3d_emu_mfma_16x16x4((a), (b), (c))
 f32x16 hp3d_emu_mfma_32x32x16_f16(f32x4 a, f32x4 b, f32x16 c);
 #define HP3D_MFMA_32x32x16_F16(a, b, c) hp3d_emu_mfma_32x32x16_f16((a), (b), (c))
+#define HP3D_MFMA_32x32x16_F16_ACC(REG_A, acc, a, b) ((acc) = hp3d_emu_mfma_32x32x16_f16((a), (b), (acc)))
+#define HP3D_MFMA_32x32x16_F16_ACC_FIRST(REG_A, acc, a, b)                                       \
+    do {                                                                                         \
+        const f32x16 _z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; \
+        (acc) = hp3d_emu_mfma_32x32x16_f16((a), (b), _z);                                        \
+    } while (0)
+static inline float hp3d_vmax(float a, float b) { return fmaxf(a, b); }
+#define HP3D_MFMA_RESULT_FENCE2(r0, r1) ((void)0)
+#define HP3D_MFMA_RESULT_FENCE4(r0, r1, r2, r3) ((void)0)
+#define HP3D_MFMA_32x32x16_F16_V(acc, a, b) HP3D_MFMA_32x32x16_F16_ACC("v", acc, a, b)
+#define HP3D_MFMA_32x32x16_F16_V_FIRST(acc, a, b) HP3D_MFMA_32x32x16_F16_ACC_FIRST("v", acc, a, b)
 // skip must be uniform over the wave (every fiber takes the same branch, so the collective MFMA stays collective)
 #define HP3D_MFMA4_UNLESS(acc, a4, b4, skip)                                                        \
     do {                                                                                           \

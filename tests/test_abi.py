@@ -150,11 +150,18 @@ def test_asm_mfmas_do_not_read_operands_a_valu_instruction_just_wrote(tmp_path):
         n_checked += 1
         bad = hz.check(lines, need=2)
         assert not bad, "%s: %d MFMA operand hazards, e.g. %r" % (name, len(bad), bad[0][2:])
+        # ... and the other direction: a VALU / LDS / VMEM read of an MFMA's VGPR result waits passes + 4 states (conv_h16_first_kernel's
+        # asm MFMAs keep their accumulators in VGPRs; HP3D_MFMA_RESULT_FENCE* in front of the first read)
+        bad = hz.check_result(lines)
+        assert not bad, "%s: %d MFMA result hazards, e.g. %r" % (name, len(bad), bad[0][1:])
     assert n_checked >= 20 and any('conv_wino4s' in k for k in kernels), n_checked
     # (the checker sees a planted violation)
     assert hz.check(['v_mov_b32_e32 v9, v3', 's_nop 0', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
     assert not hz.check(['v_mov_b32_e32 v9, v3', 's_nop 1', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
     assert not hz.check(['v_mov_b32_e32 v9, v3', 'v_add_u32_e32 v1, v2, v3', 'ds_read_b64 v[20:21], v1', 'v_mfma_f32_16x16x32_bf16 a[0:3], v[8:11], v[4:7], a[0:3]'], need=2)
+    assert hz.check_result(['v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]', 's_nop 7', 'v_add_f32_e32 v40, v3, v41'])
+    assert not hz.check_result(['v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]', 's_nop 15', 'v_add_f32_e32 v40, v3, v41'])
+    assert not hz.check_result(['v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]', 'v_add_f32_e32 v40, v42, v41', 'v_mfma_f32_32x32x16_f16 v[0:15], v[20:23], v[24:27], v[0:15]'])
 
 
 def test_hot_kernels_have_no_waterfall_loops_and_no_scratch_in_their_loops(tmp_path):

@@ -299,6 +299,20 @@ def test_f16_trunks_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights)
             _, small_unfused = emu_engine.handsegnet(img, want_small=True)
             emu_engine.set_option('f16_fuse12', '1')
             assert np.array_equal(small, small_unfused)
+        # the fused block's two forms (round 6): filter ring, two workgroups per CU / conv1_2's filters resident in registers, one workgroup per
+        # CU walking its items with the next patch built between the K-steps -- 3 images x 6 tiles on the interpreter's 3 CUs = 6 items per
+        # workgroup (prologue, steady state, the dry run past the last item), ragged tiles, image borders inside the halo
+        img = synth.make_batch(6, 3, 24, 40)
+        outs = {}
+        for form in ('ring', 'resident'):
+            emu_engine.set_option('f16_fuse12', form)
+            n0 = emu_engine.counter('conv_h16_first_resident_launches')
+            _, outs[form] = emu_engine.handsegnet(img, want_small=True)
+            assert emu_engine.counter('conv_h16_first_resident_launches') - n0 == (1 if form == 'resident' else 0)
+        emu_engine.set_option('f16_fuse12', '0')
+        _, unfused = emu_engine.handsegnet(img, want_small=True)
+        assert np.array_equal(outs['ring'], unfused) and np.array_equal(outs['resident'], unfused)
+        emu_engine.set_option('f16_fuse12', '1')
         crop = synth.make_batch(9, 1, 16, 16)
         for a, b in zip(net.inference_pose2d(crop), N.posenet2d(synth_weights, crop, acc=np.float64, f16=True)):
             assert np.abs(a - b).max() < 2e-3

@@ -923,6 +923,17 @@ def test_f16_trunk_kernel_conv_h16_vs_general_kernel(gpu_engine, synth_weights):
         assert np.array_equal(out['h16_force'][0], small_unfused)
         for a, b in zip(out['h16_force'][1], sms_unfused):
             assert np.array_equal(a, b)
+        # round 6: the fused block's two forms (filter ring, two workgroups per CU / conv1_2's filters resident in registers, one workgroup per
+        # CU with the next patch built between the K-steps), each forced, on ragged tiles (232 = 14.5 tiles): the two-launch result bit for bit
+        for form in ('ring', 'resident'):
+            gpu_engine.set_option('f16_fuse12', form)
+            n0 = gpu_engine.counter('conv_h16_first_resident_launches')
+            _, small_f = gpu_engine.handsegnet(img, want_small=True)
+            sms_f = net16.inference_pose2d(crop)
+            assert gpu_engine.counter('conv_h16_first_resident_launches') - n0 == (2 if form == 'resident' else 0), form
+            assert np.array_equal(small_f, small_unfused), form
+            for a, b in zip(sms_f, sms_unfused):
+                assert np.array_equal(a, b), form
     finally:
         gpu_engine.set_option('f16_fuse12', '1')
         gpu_engine.set_option('f16_k7k1', '1')
@@ -952,6 +963,14 @@ def test_f16_config_c5_shape_properties(gpu_engine, synth_weights):
         _, small_unfused = gpu_engine.handsegnet(img, want_small=True)
         gpu_engine.set_option('f16_fuse12', '1')
         assert np.array_equal(small, small_unfused)
+        # ... and that was the filter-resident form (9600 items >= 4 per CU); the ring form gives the same bits
+        n0 = gpu_engine.counter('conv_h16_first_resident_launches')
+        gpu_engine.handsegnet(img, want_small=True)
+        assert gpu_engine.counter('conv_h16_first_resident_launches') - n0 == 1
+        gpu_engine.set_option('f16_fuse12', 'ring')
+        _, small_ring = gpu_engine.handsegnet(img, want_small=True)
+        gpu_engine.set_option('f16_fuse12', '1')
+        assert np.array_equal(small, small_ring)
         o_h16 = gpu_engine.infer_full(img, hs)
         gpu_engine.set_option('f16_impl', 'mfma')
         _, small_mfma = gpu_engine.handsegnet(img, want_small=True)

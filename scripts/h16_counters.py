@@ -21,8 +21,11 @@ def load(path):
         if 'conv_h16' not in r['Kernel_Name']:
             continue
         k = r['Kernel_Name']
-        k = k[k.find('conv_h16_kernel'):]
-        k = k[:k.find('(')] if '(' in k else k
+        if 'conv_h16_first_kernel' in k:
+            k = 'conv_h16_first_kernel: fused first block, filters resident in registers, 1 workgroup per CU'      # (round 6; no template arguments)
+        else:
+            k = k[k.find('conv_h16_kernel'):]
+            k = k[:k.find('(')] if '(' in k else k
         d = rows[int(r['Dispatch_Id'])]
         d['k'] = k
         d[r['Counter_Name']] = float(r['Counter_Value'])

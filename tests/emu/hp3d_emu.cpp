@@ -1,5 +1,7 @@
 // hp3d_emu.cpp -- fiber scheduler + collectives + HIP runtime stand-ins (see hp3d_emu.h).
 #include "hp3d_emu.h"
+#include <map>
+#include <mutex>
 
 #include <chrono>
 #include <vector>
@@ -261,11 +263,42 @@ void hp3d_emu_run(dim3 grid, dim3 block, size_t shmem, const std::function<void(
 }
 
 // ---- HIP runtime stand-ins ---------------------------------------------------------------
+// Large blocks are kept and handed out again instead of going back to the OS: in the sandboxes the CPU suite runs in, growing a process by
+// another gigabyte of fresh pages costs 5-7 s (the first one 0.5 s), and every engine a test opens allocates a 1.3 GB weight blob.
+namespace {
+std::mutex g_mem_mutex;
+std::map<void*, size_t> g_live;                     // big blocks handed out
+std::multimap<size_t, void*> g_spare;               // big blocks given back, by size
+constexpr size_t BIG = (size_t)8 << 20;
+size_t g_spare_bytes = 0;                          // (kept below 6 GB)
+}
 hipError_t hipMalloc(void** p, size_t n) {
-    *p = aligned_alloc(256, (n + 255) / 256 * 256);
+    n = (n + 255) / 256 * 256;
+    if (n >= BIG) {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        auto it = g_spare.lower_bound(n);
+        if (it != g_spare.end() && it->first <= n + n / 4) {
+            *p = it->second; g_live[*p] = it->first; g_spare_bytes -= it->first; g_spare.erase(it);
+            return hipSuccess;
+        }
+    }
+    *p = aligned_alloc(256, n);
+    if (*p && n >= BIG) { std::lock_guard<std::mutex> lk(g_mem_mutex); g_live[*p] = n; }
     return *p ? hipSuccess : hipErrorUnknown;
 }
-hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipFree(void* p) {
+    {
+        std::lock_guard<std::mutex> lk(g_mem_mutex);
+        auto it = g_live.find(p);
+        if (it != g_live.end()) {
+            const size_t n = it->second;
+            g_live.erase(it);
+            if (g_spare_bytes + n <= ((size_t)6 << 30)) { g_spare.emplace(n, p); g_spare_bytes += n; return hipSuccess; }
+        }
+    }
+    free(p);
+    return hipSuccess;
+}
 hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }

@@ -60,11 +60,12 @@ def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
     from hand3d_amd import Engine
     from hand3d_amd.nets.ColorHandPose3DNetwork import pickle_to_npz, read_weight_file
     paths = synth.write_weight_files(str(tmp_path), synth_weights)
-    lean = ColorHandPose3DNetwork(engine=emu_engine)
-    lean.init(None, weight_files=paths)
+    lean = ColorHandPose3DNetwork(engine=Engine(0, path=emu_engine.lib._name))
+    lean.init(None, weight_files=paths, exclude_var_list=['HandSegNet', 'PoseNet2D'])      # (the two small nets: every init packs what it loads)
     assert lean.weight_dict == {}, "weights are only retained on request"
     with pytest.raises(AssertionError, match="keep_weights"):
         lean.export_npz(str(tmp_path / 'no.npz'))
+    lean.engine.close()            # (one engine at a time beside the session's: each holds a 1.3 GB weight blob)
     net = ColorHandPose3DNetwork(engine=emu_engine, keep_weights=True)
     net.init(None, weight_files=paths)
     npz = str(tmp_path / 'all.npz')
@@ -76,7 +77,8 @@ def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
     # the converter on the files gives the same archive content; exclusion applies to .npz files like to pickles
     npz2 = str(tmp_path / 'conv.npz')
     keys = pickle_to_npz(paths, npz2)
-    assert keys == sorted(synth_weights) and all(np.array_equal(read_weight_file(npz2)[k], back[k]) for k in keys)
+    back2 = read_weight_file(npz2)
+    assert keys == sorted(synth_weights) and all(np.array_equal(back2[k], back[k]) for k in keys)
     e2 = Engine(0, path=emu_engine.lib._name)
     net2 = ColorHandPose3DNetwork(engine=e2)
     net2.init(None, weight_files=[npz])
@@ -94,16 +96,18 @@ def test_npz_weights_round_trip(tmp_path, emu_engine, synth_weights):
             assert np.array_equal(x, y)
         for x, y in zip(ea.pose3d(sm, hs), eb.pose3d(sm, hs)):
             assert np.array_equal(x, y)
+    e2.close()
     e3 = Engine(0, path=emu_engine.lib._name)
     net3 = ColorHandPose3DNetwork(engine=e3)
-    net3.init(None, weight_files=[npz], exclude_var_list=['PosePrior', 'ViewpointNet'])
-    assert e3.nets_mask() & 15 == 3
+    net3.init(None, weight_files=[npz], exclude_var_list=['HandSegNet', 'PoseNet2D'])
+    assert e3.nets_mask() & 15 == 12
+    with pytest.raises(AssertionError, match="File not found."):
+        net3.init(None, weight_files=[str(tmp_path / 'missing.npz')])
+    e3.close()
     pp = PosePriorNetwork('direct', engine=Engine(0, path=emu_engine.lib._name))
     pp.init(None, weight_files=[npz], exclude_var_list=['HandSegNet', 'PoseNet2D', 'ViewpointNet'])
     assert pp.engine.nets_mask() & 15 == 4
-    with pytest.raises(AssertionError, match="File not found."):
-        net3.init(None, weight_files=[str(tmp_path / 'missing.npz')])
-    e2.close(); e3.close(); pp.engine.close()
+    pp.engine.close()
 
 
 def test_error_behaviour(emu_engine, synth_weights):

@@ -23,8 +23,10 @@
 //   * persistent grid over (image, tile, cout block) items; edges and ragged tiles are out-of-range buffer offsets.
 //   * round 4: the filter size is a template parameter KS -- PoseNet2D's 7x7 score-map stages (nets/ColorHandPose3DNetwork.py:206-215) and the 1x1
 //     layers with >= 64 couts take the single-buffer forms with a patch of (16 + KS - 1)^2 pixels and 4 KS^2 K-steps per chunk.
-// Measured (profiles/r04_h16_counters.md): 0.42-0.48 of the 2.5 PF dense peak per 3x3 instantiation at the config-5 shape (the 7x7 form: 0.53); the
-// matrix pipe is busy 0.66-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load.
+//   * round 6: the fused first block (conv1_1 + conv1_2 + pool) has a second form, conv_h16_first_kernel below: one workgroup per CU, conv1_2's whole
+//     filter resident in registers, the next tile's patch built between the MFMAs of the current one (3.89 -> 3.21 ms at the config-5 shape).
+// Measured (profiles/r06_h16_counters.md): 0.43-0.48 of the 2.5 PF dense peak per 3x3 instantiation at the config-5 shape (the 7x7 form: 0.53); the
+// matrix pipe is busy 0.67-0.73 of the time at the 1.5-1.6 GHz the chip sustains under this load (a register-only loop of the same MFMA: 2.05 GHz).
 #include "hp3d_common.h"
 #include <algorithm>
 

@@ -3,6 +3,7 @@
 # smoke(), the config-5 line + its PMC traffic passes, and the driver's exact command (-> profiles/r06_* via scripts/summarize_prof.py,
 # scripts/h16_counters.py and scripts/make_configs_md.py)
 TAG=${1:-r06}
+# (before the call, here: `git rev-parse --short HEAD > .tree_id` -- the snapshot carries no .git, the traffic files' stamps name the tree from it)
 bash scripts/gpu_round.sh $TAG pmc
 OUT=gpurun_out/$TAG
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; echo "smoke exit $?"; tail -3 $OUT/smoke.log

@@ -17,6 +17,9 @@ from collections import defaultdict
 def _tree_id():
     if os.environ.get('HP3D_TREE_ID'):
         return os.environ['HP3D_TREE_ID']
+    root0 = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.path.exists(os.path.join(root0, '.tree_id')):          # written next to the snapshot before a gpurun visit (the GPU box has no .git)
+        return open(os.path.join(root0, '.tree_id')).read().strip() or 'unknown'
     try:
         import subprocess
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

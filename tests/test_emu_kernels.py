@@ -300,9 +300,10 @@ def test_f16_trunks_on_conv_h16_kernel_on_interpreter(emu_engine, synth_weights)
             emu_engine.set_option('f16_fuse12', '1')
             assert np.array_equal(small, small_unfused)
         # the fused block's two forms (round 6): filter ring, two workgroups per CU / conv1_2's filters resident in registers, one workgroup per
-        # CU walking its items with the next patch built between the K-steps -- 2 images x 6 tiles on the interpreter's 3 CUs = 4 items per
-        # workgroup (prologue, steady state, the dry run past the last item), ragged tiles, image borders inside the halo
-        img = synth.make_batch(6, 2, 24, 40)
+        # CU walking its items with the next patch built between the K-steps -- 3 x 4 tiles on the interpreter's 3 CUs = 4 items per
+        # workgroup (prologue, steady state, the dry run past the last item); border tiles (zero padding inside the halo) and two interior
+        # ones, ragged bottom row and right column (40 = 2.5, 56 = 3.5 tiles)
+        img = synth.make_batch(6, 1, 40, 56)
         outs = {}
         for form in ('ring', 'resident'):
             emu_engine.set_option('f16_fuse12', form)

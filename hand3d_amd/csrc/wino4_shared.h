@@ -22,14 +22,16 @@ constexpr int W4_NP = 36;                          // planes of F(4x4,3x3)
 //   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 template <typename T>
 __device__ __forceinline__ void w4_bt_t(T& x0, T& x1, T& x2, T& x3, T& x4, T& x5) {
+    // twelve operations (rows 1 / 2 = a +- b with a = x4 - 4 x2, b = x3 - 4 x1; rows 3 / 4 = c +- 2 f with c = x4 - x2, f = x3 - x1); until round 6 the sums and
+    // differences of the pairs were formed first: fourteen
     const T t0 = (4.f * x0 + x4) - 5.f * x2;
     const T t5 = (4.f * x1 + x5) - 5.f * x3;
-    const T s12 = x1 + x2, d12 = x1 - x2, s34 = x3 + x4, d43 = x4 - x3, d31 = x3 - x1, d42 = x4 - x2;
+    const T a = x4 - 4.f * x2, b = x3 - 4.f * x1, c = x4 - x2, f = x3 - x1;
     x0 = t0;
-    x1 = s34 - 4.f * s12;
-    x2 = d43 + 4.f * d12;
-    x3 = d42 + 2.f * d31;
-    x4 = d42 - 2.f * d31;
+    x1 = a + b;
+    x2 = a - b;
+    x3 = c + 2.f * f;
+    x4 = c - 2.f * f;
     x5 = t5;
 }
 // (packed FMAs: scalar float transforms were re-measured on the final kernel in round 4, 2.3 % slower)

@@ -283,6 +283,15 @@ void conv_wino4_kernel(const ConvParams p) {
             else if (NSUB > 1 && ncs == 0) loader_shift(nsub_);
             const int wstep_b = W4_CK * 4;
             const int wsoff = NSUB > 1 ? HP3D_READFIRSTLANE(ncs * wstep_b) : ncs * wstep_b;
+            // The 36 window addresses (row term + column term) in ONE block here, at the top of the step, where the wave waits for its first A
+            // fragments anyway -- not one v_add_u32 in front of each load between the MFMA pairs: a float32 MFMA and a VALU instruction of the same
+            // wave do not overlap, and a lone VALU result feeding a load address between MFMAs costs 15 ns in isolation (profiles/r06_tuning_notes.md
+            // section 7; in situ the adds were worth 1.0-1.5 %).  An address lives in the register pair its load fills.
+            int wa[36];
+            if (NSUB == 1) {
+#pragma unroll
+                for (int e = 0; e < 36; ++e) { wa[e] = (int)((unsigned)ro[e / 6] + (unsigned)co[e % 6]); HP3D_OPAQUE_V(wa[e]); }
+            }
             // The plane as four PAIRS of MFMAs (one k quad, both tile halves) with ONE of the plane's other instructions after each: the next
             // plane's A fragments | window load | window load | the weight fragment for the slot this plane releases.  Each issues under the
             // 64 matrix-core cycles of the pair in front of it; as one block of eight with everything at the plane boundary the wave spent
@@ -329,7 +338,7 @@ void conv_wino4_kernel(const ConvParams p) {
                                 const int wk = pl * W4_WPP + (e - 1) * (W4_WPP / 2) + j;
                                 if (wk < 36) {
                                     const int we = W4_ISSUE_ELEM(wk < 36 ? wk : 0);
-                                    d[we] = W4_WLOAD(irsrc, (int)((unsigned)ro[we / 6] + (unsigned)co[we % 6]), wsoff);
+                                    d[we] = W4_WLOAD(irsrc, wa[we], wsoff);
                                 }
                             }
                         }

@@ -154,7 +154,7 @@ int hp3d_sync(hp3d_ctx* ctx);
  *          "wino4_split"  = "0" (default) | "auto" | "1" (round 6): the 3x3 / stride-1 trunk layers with Cin >= 128 whose launch fills the chip run
  *                            Winograd F(4x4,3x3) with the plane products on v_mfma_f32_16x16x32_bf16 over THREE bfloat16 pieces per operand (six
  *                            products, float32 accumulate: conv_wino4s.hip) | never | wherever the shape allows (tests).  Float32 in and out; per
- *                            layer as exact as "wino4" (0.7 ... 1.6x its error per shape, profiles/r06_split_numerics.md) and 1.03-1.09x its speed:
+ *                            layer as exact as "wino4" (0.7 ... 1.6x its error per shape, profiles/r06_split_numerics.md) and, when built, 1.03-1.09x its (since conv_wino4's late round-6 gains: 0.98x) speed:
  *                            an option, not the default;
  *          "fc_tail"      = "1" (default) | "0" (round 6): ViewpointNet's three FC layers (ColorHandPose3DNetwork.py:299-307) as two launches -- the K slices
  *                            of fc_vp0, then their fixed-order reduction + fc_vp1 + fc_vp_u in one -- | as three partial + reduce pairs.  Same sums up
